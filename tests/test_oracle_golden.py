@@ -1,0 +1,195 @@
+"""Pins oracle/orbit2_oracle.py against fixtures generated from the reference's own modules
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import orbit2_oracle as O
+
+CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+TOL = 2e-5
+
+
+def rel(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12))
+
+
+@pytest.fixture(scope="module")
+def comp(golden_dir):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "components_tiny.npz")).items()}
+
+
+def test_patch_embed(comp):
+    x = comp["pe.x"].clone().requires_grad_()
+    w = comp["pe.w"].clone().requires_grad_()
+    b = comp["pe.b"].clone().requires_grad_()
+    y = O.patch_embed(x, w, b, 2)
+    assert rel(y, comp["pe.y"]) < TOL
+    y.backward(comp["pe.go"])
+    assert rel(x.grad, comp["pe.gx"]) < TOL and rel(w.grad, comp["pe.gw"]) < TOL and rel(b.grad, comp["pe.gb"]) < TOL
+
+
+def test_variable_aggregation(comp):
+    bl, v, d = comp["va.x"].shape
+    x = comp["va.x"].clone().requires_grad_()
+    t = {k: comp["va." + k].clone().requires_grad_() for k in ("vq", "wq", "wkv", "wp", "bp")}
+    # oracle takes [B, V, L, D]; fixture is [B*L, V, D] -> B=1, L=bl
+    y = O.variable_aggregation(x.permute(1, 0, 2).unsqueeze(0), t["vq"], t["wq"], t["wkv"], t["wp"], t["bp"], 4)
+    assert rel(y.reshape(bl, 1, d), comp["va.y"]) < TOL
+    assert rel(y.reshape(bl, 1, d), comp["va.y_default"]) < TOL
+    y.backward(comp["va.go"].reshape(1, bl, d))
+    assert rel(x.grad, comp["va.gx"]) < TOL
+    for k in ("vq", "wq", "wkv", "wp", "bp"):
+        assert rel(t[k].grad, comp["va.g" + k]) < 5e-5, k
+
+
+def test_attention(comp):
+    x = comp["at.x"].clone().requires_grad_()
+    t = {k: comp["at." + k].clone().requires_grad_() for k in ("wqkv", "bqkv", "wp", "bp")}
+    y = O.attention(x, t["wqkv"], t["bqkv"], t["wp"], t["bp"], 4)
+    assert rel(y, comp["at.y"]) < TOL and rel(y, comp["at.y_default"]) < TOL
+    y.backward(comp["at.go"])
+    assert rel(x.grad, comp["at.gx"]) < TOL
+    for k in t:
+        assert rel(t[k].grad, comp["at.g" + k]) < 5e-5, k
+
+
+def test_mlp(comp):
+    x = comp["ml.x"].clone().requires_grad_()
+    t = {k: comp["ml." + k].clone().requires_grad_() for k in ("w1", "b1", "w2", "b2")}
+    y = O.mlp(x, t["w1"], t["b1"], t["w2"], t["b2"])
+    assert rel(y, comp["ml.y"]) < TOL
+    y.backward(comp["ml.go"])
+    assert rel(x.grad, comp["ml.gx"]) < TOL
+    for k in t:
+        assert rel(t[k].grad, comp["ml.g" + k]) < 5e-5, k
+
+
+def test_block(comp):
+    sd = {"b." + k[5:]: v.clone().requires_grad_() for k, v in comp.items() if k.startswith("bk.p.")}
+    x = comp["bk.x"].clone().requires_grad_()
+    y = O.block(x, sd, "b.", 4)
+    assert rel(y, comp["bk.y"]) < TOL
+    y.backward(comp["bk.go"])
+    assert rel(x.grad, comp["bk.gx"]) < TOL
+    for k, v in sd.items():
+        assert rel(v.grad, comp["bk.g." + k[2:]]) < 5e-5, k
+
+
+def test_pos_embed(comp):
+    assert rel(O.sincos_2d(64, 4, 8), comp["pos.sincos_4x8_64"]) < 1e-6
+    assert rel(O.sincos_2d(256, 16, 32), comp["pos.sincos_16x32_256"]) < 1e-6
+    pe = comp["pos.in"]
+    assert torch.equal(O.pos_embed_for_grid(pe, 2, (8, 16)), comp["pos.same"])
+    assert rel(O.pos_embed_for_grid(pe, 2, (24, 48)), comp["pos.up_12x24"]) < TOL
+    assert rel(O.pos_embed_for_grid(pe, 2, (4, 8)), comp["pos.down_2x4"]) < TOL
+
+
+CASES = {
+    "v5c1": dict(in_vars=CONST + ["total_precipitation_24hr"], out_vars=["total_precipitation_24hr"],
+                 grid=(16, 32), D=64, depth=2, heads=4, dd=2),
+    "v7c3": dict(in_vars=CONST + ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"],
+                 out_vars=["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"],
+                 grid=(16, 32), D=64, depth=2, heads=2, dd=1),
+    "v6c2_regrid": dict(in_vars=["2m_temperature", "lattitude", "orography", "landcover", "land_sea_mask",
+                                 "total_precipitation_24hr"],
+                        out_vars=["total_precipitation_24hr", "2m_temperature"],
+                        default_vars=CONST + ["2m_temperature", "10m_u_component_of_wind",
+                                              "total_precipitation_24hr"],
+                        grid=(16, 32), D=32, depth=1, heads=2, dd=1),
+}
+VW = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0,
+      "2m_temperature": 10.0}
+
+
+def load_case(golden_dir, tag):
+    c = CASES[tag]
+    z = np.load(os.path.join(golden_dir, "model_%s.npz" % tag))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    cfg = O.Config(c.get("default_vars", c["in_vars"]), c["grid"], len(c["out_vars"]), c["D"], c["depth"], c["dd"],
+                   c["heads"], spatial_resolution=156.0)
+    return c, z, sd, cfg
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_model_forward_loss_grads(golden_dir, tag):
+    c, z, sd, cfg = load_case(golden_dir, tag)
+    sd = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    pred = O.forward(sd, cfg, x, c["in_vars"], c["out_vars"])
+    assert rel(pred, z["pred"]) < TOL
+    yhat = O.clip_replace_constant(y, pred, c["out_vars"])
+    tgt = O.crop_target(y, yhat)
+    lw = O.lat_weights(z["lat"])
+    assert rel(O.mse(yhat, tgt, c["out_vars"], VW), z["loss.mse"]) < TOL
+    assert rel(O.bayesian_tv(yhat, tgt, c["out_vars"], VW), z["loss.bayesian_tv"]) < TOL
+    assert rel(O.mse(yhat, tgt, c["out_vars"], VW, False, lw), z["loss.lat_mse"]) < TOL
+    for lname in ("mse", "bayesian_tv"):
+        for v in sd.values():
+            v.grad = None
+        O.LOSSES[lname](yhat, tgt, c["out_vars"], VW, True).backward(retain_graph=True)
+        n = 0
+        for k, v in sd.items():
+            gk = "g.%s.%s" % (lname, k)
+            if gk in z.files:
+                assert rel(v.grad, z[gk]) < 2e-4, gk
+                n += 1
+        assert n > 20
+
+
+@pytest.mark.parametrize("tag", ["v5c1", "v6c2_regrid"])
+def test_adamw_trajectory(golden_dir, tag):
+    c, z, sd, cfg = load_case(golden_dir, tag)
+    names = [k for k in sd]
+    p = {k: sd[k].clone().requires_grad_() for k in names}
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    traj = []
+    for step in range(1, 4):
+        loss = O.training_loss(p, cfg, x, y, c["in_vars"], c["out_vars"], "bayesian_tv", VW)
+        traj.append(float(loss))
+        grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+        with torch.no_grad():
+            for k, g in zip(names, grads):
+                if g is not None:
+                    O.adamw_step(p[k], g, m[k], v[k], step, 5e-4, 0.9, 0.99, 1e-8, 1e-5)
+    assert np.allclose(traj, z["adamw.loss_traj"], rtol=2e-5)
+    assert rel(p["head.0.weight"], z["adamw.p_after.head.0.weight"]) < 1e-4
+    assert rel(p["var_query"], z["adamw.p_after.var_query"]) < 1e-4
+
+
+def test_losses_raw(golden_dir):
+    z = np.load(os.path.join(golden_dir, "losses.npz"))
+    names = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+    vw = {"2m_temperature_min": 10.0, "2m_temperature_max": 10.0, "total_precipitation_24hr": 1.0}
+    lw = O.lat_weights(z["lat"])
+    tg = torch.from_numpy(z["target"])
+    for lname, fn, kw in (("mse", O.mse, {}), ("bayesian_tv", O.bayesian_tv, {}), ("lat_mse", O.mse, {"lat_w": lw}),
+                          ("lat_bayesian_tv", O.bayesian_tv, {"lat_w": lw})):
+        pr = torch.from_numpy(z["pred"]).clone().requires_grad_()
+        full = fn(pr, tg, names, vw, False, **kw)
+        assert rel(full, z[lname]) < TOL, lname
+        full[-1].backward()
+        assert rel(pr.grad, z[lname + ".gpred"]) < TOL, lname
+        assert rel(fn(pr, tg, None, None, False, **kw), z[lname + ".noweights"]) < TOL
+
+
+def test_lr_schedule(golden_dir):
+    z = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
+    a = [O.warmup_cosine_lr(e, 5e-4, 2, 100, 1e-7, 1e-8) for e in range(100)]
+    assert np.allclose(a, z["lr_w2_m100"], rtol=1e-9, atol=1e-15)
+    b = [O.warmup_cosine_lr(e, 2e-4, 5, 30, 1e-6, 1e-7) for e in range(30)]
+    assert np.allclose(b, z["lr_w5_m30"][:30], rtol=1e-9, atol=1e-15)
+
+
+def test_flop_model_matches_survey():
+    # interm_1b @ 128x256 -> F_fwd = 2.950e13
+    f = O.forward_flops(8192, 23, 3072, 8, 4, 3, 128, 256, 24)
+    assert abs(f / 2.950e13 - 1) < 2e-3
+    f = O.forward_flops(512, 23, 1024, 8, 4, 3, 32, 64, 16)
+    assert abs(f / 1.679e11 - 1) < 2e-3
