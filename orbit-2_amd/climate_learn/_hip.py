@@ -1,0 +1,331 @@
+"""ctypes binding of liborbit2_hip.so (C ABI in include/orbit2_hip.h).
+
+This is the ONLY compute backend of the package: there is no CPU or eager fallback.  Every wrapper
+checks that its operands are contiguous device tensors of the expected dtype and passes raw device
+pointers plus torch's current HIP stream across the ABI.  A missing library or a non-zero return
+code raises immediately."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liborbit2_hip.so")
+_lib = None
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+        ("a_kc", C.c_int), ("b_kc", C.c_int),
+        ("bias", C.c_void_p),
+        ("act", C.c_int),
+        ("save_pre", C.c_void_p),
+        ("dgelu_pre", C.c_void_p),
+        ("drop_p", C.c_float),
+        ("seed", C.c_uint64),
+        ("rowscale", C.c_void_p),
+        ("rows_per_scale", C.c_int),
+        ("residual", C.c_void_p),
+        ("ldr", C.c_int), ("res_mod", C.c_int), ("res_first", C.c_int),
+        ("out_fp32", C.c_int),
+        ("beta", C.c_float),
+    ]
+
+
+def lib():
+    """Load the shared library once; fail loudly if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                "liborbit2_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        if _lib.orbit2_abi_version() != 1:
+            raise HipBackendError("liborbit2_hip.so ABI version mismatch")
+    return _lib
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(rc: int, name: str):
+    if rc != 0:
+        raise HipBackendError("%s failed with code %d (-1 bad argument, -2 launch error, -3 unsupported)" % (name, rc))
+
+
+def _dev(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise HipBackendError("%s must be a GPU tensor (HIP backend has no CPU path)" % name)
+    if t.dtype != dtype:
+        raise HipBackendError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise HipBackendError("%s must be contiguous" % name)
+    return t
+
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None, dgelu_pre=None,
+         drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0, res_first=False,
+         beta=0.0):
+    """out[M,N] = epilogue(A x B); see include/orbit2_hip.h:orbit2_gemm_bf16."""
+    for t, nm in ((A, "A"), (B, "B")):
+        _dev(t, BF, nm)
+    if out.dtype not in (BF, F32) or not out.is_cuda:
+        raise HipBackendError("gemm out must be a bf16/fp32 GPU tensor")
+    a = GemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, lda, ldb, ldc
+    a.a_kc, a.b_kc = int(a_kc), int(b_kc)
+    a.bias = None if bias is None else _dev(bias, BF, "bias").data_ptr()
+    a.act = act
+    a.save_pre = None if save_pre is None else _dev(save_pre, BF, "save_pre").data_ptr()
+    a.dgelu_pre = None if dgelu_pre is None else _dev(dgelu_pre, BF, "dgelu_pre").data_ptr()
+    a.drop_p, a.seed = float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
+    a.rowscale = None if rowscale is None else _dev(rowscale, F32, "rowscale").data_ptr()
+    a.rows_per_scale = rows_per_scale
+    a.residual = None if residual is None else _dev(residual, BF, "residual").data_ptr()
+    a.ldr, a.res_mod, a.res_first = ldr, res_mod, int(res_first)
+    a.out_fp32 = int(out.dtype == F32)
+    a.beta = float(beta)
+    _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
+    return out
+
+
+def sgemm(A, B, out, M, N, K, lda, ldb, ldc, ta=False, tb=False, alpha=1.0, beta=0.0):
+    for t, nm in ((A, "A"), (B, "B"), (out, "C")):
+        _dev(t, F32, nm)
+    _chk(lib().orbit2_sgemm_f32(_p(A), _p(B), _p(out), M, N, K, lda, ldb, ldc, int(ta), int(tb), C.c_float(alpha),
+                                C.c_float(beta), _stream()), "orbit2_sgemm_f32")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    _dev(x, BF, "x"); _dev(gamma, BF, "gamma"); _dev(beta, BF, "beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=F32, device=x.device)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    _chk(lib().orbit2_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, C.c_float(eps),
+                                    _stream()), "orbit2_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, beta_acc=0.0):
+    _dev(dy, BF, "dy"); _dev(x, BF, "x"); _dev(gamma, BF, "gamma")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x)
+    n = lib().orbit2_layernorm_bwd_ws_floats(rows, D)
+    ws = torch.empty(n, dtype=F32, device=x.device)
+    fp32 = int(dgamma.dtype == F32)
+    _chk(lib().orbit2_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma),
+                                    _p(dbeta), fp32, C.c_float(beta_acc), _p(ws), n, rows, D, _stream()),
+         "orbit2_layernorm_bwd")
+    return dx
+
+
+def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0):
+    _dev(qkv, BF, "qkv")
+    out = torch.empty(B, L, H * d, dtype=BF, device=qkv.device)
+    lse = torch.empty(B, H, L, dtype=F32, device=qkv.device)
+    _chk(lib().orbit2_attn_fwd(_p(qkv), _p(out), _p(lse), B, L, H, d, C.c_float(drop_p), C.c_uint64(seed), _stream()),
+         "orbit2_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, L, H, d, drop_p=0.0, seed=0):
+    _dev(qkv, BF, "qkv"); _dev(out, BF, "out"); _dev(dout, BF, "dout"); _dev(lse, F32, "lse")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, L, dtype=F32, device=qkv.device)
+    _chk(lib().orbit2_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, L, H, d,
+                               C.c_float(drop_p), C.c_uint64(seed), _stream()), "orbit2_attn_bwd")
+    return dqkv
+
+
+def varagg_fwd(x, stab, gtab, H, D):
+    _dev(x, F32, "x"); _dev(stab, F32, "stab"); _dev(gtab, F32, "gtab")
+    B, V, h, w = x.shape
+    ntok = B * (h // 2) * (w // 2)
+    z = torch.empty(ntok, D, dtype=BF, device=x.device)
+    attw = torch.empty(ntok, H, V, dtype=F32, device=x.device)
+    _chk(lib().orbit2_varagg_fwd(_p(x), _p(stab), _p(gtab), _p(z), _p(attw), B, V, h, w, H, D, _stream()),
+         "orbit2_varagg_fwd")
+    return z, attw
+
+
+def varagg_bwd(x, gtab, attw, dz, H, D):
+    _dev(x, F32, "x"); _dev(gtab, F32, "gtab"); _dev(attw, F32, "attw"); _dev(dz, BF, "dz")
+    B, V, h, w = x.shape
+    dstab = torch.zeros(H, V, 5, dtype=F32, device=x.device)
+    dgtab = torch.zeros(V, 5, D, dtype=F32, device=x.device)
+    _chk(lib().orbit2_varagg_bwd(_p(x), _p(gtab), _p(attw), _p(dz), _p(dstab), _p(dgtab), B, V, h, w, H, D, _stream()),
+         "orbit2_varagg_bwd")
+    return dstab, dgtab
+
+
+def dropout_bwd(dy, M, N, drop_p, seed, rowscale=None, rows_per_scale=0, out=None):
+    _dev(dy, BF, "dy")
+    out = torch.empty_like(dy) if out is None else out
+    _chk(lib().orbit2_dropout_bwd(_p(dy), _p(out), M, N, C.c_float(drop_p), C.c_uint64(seed), _p(rowscale),
+                                  rows_per_scale, _stream()), "orbit2_dropout_bwd")
+    return out
+
+
+def colsum(x, M, N, ldx, out, beta=0.0):
+    if x.dtype not in (BF, F32):
+        raise HipBackendError("colsum input must be bf16/fp32")
+    n = lib().orbit2_colsum_ws_floats(M, N)
+    ws = torch.empty(n, dtype=F32, device=x.device)
+    _chk(lib().orbit2_colsum(_p(x), int(x.dtype == F32), M, N, ldx, _p(out), int(out.dtype == F32), C.c_float(beta),
+                             _p(ws), n, _stream()), "orbit2_colsum")
+    return out
+
+
+def batch_sum(x, B, rows, N, out, beta=0.0):
+    _dev(x, BF, "x")
+    _chk(lib().orbit2_batch_sum(_p(x), _p(out), B, rows, N, int(out.dtype == F32), C.c_float(beta), _stream()),
+         "orbit2_batch_sum")
+    return out
+
+
+def cast_to_bf16(src, dst=None):
+    _dev(src, F32, "src")
+    dst = torch.empty(src.shape, dtype=BF, device=src.device) if dst is None else dst
+    _chk(lib().orbit2_cast_f32_to_bf16(_p(src), _p(dst), C.c_int64(src.numel()), _stream()), "orbit2_cast_f32_to_bf16")
+    return dst
+
+
+def cast_to_f32(src, dst=None):
+    _dev(src, BF, "src")
+    dst = torch.empty(src.shape, dtype=F32, device=src.device) if dst is None else dst
+    _chk(lib().orbit2_cast_bf16_to_f32(_p(src), _p(dst), C.c_int64(src.numel()), _stream()), "orbit2_cast_bf16_to_f32")
+    return dst
+
+
+def add_rowvec(a, vec, rows, N):
+    _dev(a, BF, "a"); _dev(vec, BF, "vec")
+    y = torch.empty_like(a)
+    _chk(lib().orbit2_add_rowvec(_p(a), _p(vec), _p(y), rows, N, _stream()), "orbit2_add_rowvec")
+    return y
+
+
+def unpatchify_fwd(t, B, Cc, h, w, p, s):
+    _dev(t, BF, "t")
+    img = torch.empty(B, Cc, h * s, w * s, dtype=F32, device=t.device)
+    _chk(lib().orbit2_unpatchify_fwd(_p(t), _p(img), B, Cc, h, w, p, s, _stream()), "orbit2_unpatchify_fwd")
+    return img
+
+
+def unpatchify_bwd(dimg, B, Cc, h, w, p, s):
+    _dev(dimg, F32, "dimg")
+    L = h * w // (p * p)
+    dt = torch.empty(B, L, Cc * (s * p) ** 2, dtype=BF, device=dimg.device)
+    _chk(lib().orbit2_unpatchify_bwd(_p(dimg), _p(dt), B, Cc, h, w, p, s, _stream()), "orbit2_unpatchify_bwd")
+    return dt
+
+
+def conv3x3_fwd(x, chan_idx, weight, bias, mode=0, r=1, addend=None):
+    _dev(x, F32, "in"); _dev(weight, F32, "weight"); _dev(bias, F32, "bias")
+    B, ctot, H, W = x.shape
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    pre = None
+    if mode == 0:
+        out = torch.empty(B, Cout, H, W, dtype=F32, device=x.device)
+    else:
+        out = torch.empty(B, Cout // (r * r), H * r, W * r, dtype=F32, device=x.device)
+        pre = torch.empty(B, Cout, H, W, dtype=F32, device=x.device)
+    Ha = Wa = 0
+    if addend is not None:
+        _dev(addend, F32, "addend")
+        Ha, Wa = addend.shape[2], addend.shape[3]
+    _chk(lib().orbit2_conv3x3_fwd(_p(x), _p(chan_idx), ctot, _p(weight), _p(bias), _p(out), _p(pre), _p(addend), Ha, Wa,
+                                  B, Cin, Cout, H, W, mode, r, _stream()), "orbit2_conv3x3_fwd")
+    return out, pre
+
+
+def conv3x3_bwd(dout, x, chan_idx, weight, pre, need_din, mode=0, r=1):
+    _dev(dout, F32, "dout"); _dev(x, F32, "in"); _dev(weight, F32, "weight")
+    B, ctot, H, W = x.shape
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    din = torch.empty(B, Cin, H, W, dtype=F32, device=x.device) if need_din else None
+    dw = torch.zeros_like(weight)
+    db = torch.zeros(Cout, dtype=F32, device=x.device)
+    _chk(lib().orbit2_conv3x3_bwd(_p(dout), _p(x), _p(chan_idx), ctot, _p(weight), _p(pre), _p(din), _p(dw), _p(db), B,
+                                  Cin, Cout, H, W, mode, r, _stream()), "orbit2_conv3x3_bwd")
+    return din, dw, db
+
+
+def clamp_channel_(img, chan):
+    _dev(img, F32, "img")
+    B, Cc, H, W = img.shape
+    _chk(lib().orbit2_clamp_channel(_p(img), B, Cc, H * W, chan, _stream()), "orbit2_clamp_channel")
+    return img
+
+
+def clamp_channel_bwd_(img_clamped, dimg, chan):
+    _dev(img_clamped, F32, "img"); _dev(dimg, F32, "dimg")
+    B, Cc, H, W = img_clamped.shape
+    _chk(lib().orbit2_clamp_channel_bwd(_p(img_clamped), _p(dimg), B, Cc, H * W, chan, _stream()),
+         "orbit2_clamp_channel_bwd")
+    return dimg
+
+
+def loss_fwd(pred, target, lat_w, chan_w, kind):
+    _dev(pred, F32, "pred"); _dev(target, F32, "target")
+    B, Cc, H, W = pred.shape
+    Ht, Wt = target.shape[2], target.shape[3]
+    out = torch.empty(Cc + 1, dtype=F32, device=pred.device)
+    ws = torch.empty((Cc * B + 1) * 64, dtype=F32, device=pred.device)
+    _chk(lib().orbit2_loss_fwd(_p(pred), _p(target), Ht, Wt, _p(lat_w), _p(chan_w), _p(out), _p(ws), B, Cc, H, W, kind,
+                               _stream()), "orbit2_loss_fwd")
+    return out
+
+
+def loss_bwd(pred, target, lat_w, chan_w, gscale, kind):
+    B, Cc, H, W = pred.shape
+    Ht, Wt = target.shape[2], target.shape[3]
+    dpred = torch.empty_like(pred)
+    _chk(lib().orbit2_loss_bwd(_p(pred), _p(target), Ht, Wt, _p(lat_w), _p(chan_w), _p(_dev(gscale, F32, "gscale")),
+                               _p(dpred), B, Cc, H, W, kind, _stream()), "orbit2_loss_bwd")
+    return dpred
+
+
+def adamw(p, m, v, g, p16, n, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, found_inf=None):
+    _dev(p, F32, "p"); _dev(m, F32, "m"); _dev(v, F32, "v")
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _chk(lib().orbit2_adamw(_p(p), _p(m), _p(v), _p(g), int(g.dtype == F32), _p(p16), C.c_int64(n), C.c_float(lr),
+                            C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(wd), C.c_float(bc1),
+                            C.c_float(bc2), C.c_float(grad_scale), _p(found_inf), _stream()), "orbit2_adamw")
+
+
+def check_finite(g, n, found_inf):
+    _chk(lib().orbit2_check_finite(_p(g), int(g.dtype == F32), C.c_int64(n), _p(found_inf), _stream()),
+         "orbit2_check_finite")
+
+
+def selftest(device="cuda") -> int:
+    buf = torch.zeros(512, dtype=torch.int32, device=device)
+    _chk(lib().orbit2_selftest(_p(buf), _stream()), "orbit2_selftest")
+    torch.cuda.synchronize()
+    return int(buf[0].item())

@@ -1,0 +1,526 @@
+// Flash-style multi-head self-attention for gfx950: forward, and a two-kernel backward
+// (dQ: query on the MFMA lane, loop over keys;  dK/dV: key on the lane, loop over queries --
+// no cross-workgroup reduction, no atomics, bitwise reproducible).
+//
+// Layout: qkv is the qkv-Linear output as stored, [B, L, 3, H, D] bf16 (reference: attention.py:50
+// reshapes+permutes it; here the kernels read it strided, so no permute copies exist); out is
+// [B, L, H, D] = the [B*L, C] operand of the proj GEMM.
+//
+// All products use v_mfma_f32_32x32x16_bf16.  A 32x32 f32 accumulator X (column on the lane, rows in the
+// 16 registers) is fed to the next MFMA as an operand without touching LDS: registers 8s..8s+7 -> bf16 is
+// the fragment of k-step s, whose k order is row(j,h) = 16s + 8(j>>2) + 4h + (j&3); the other operand is
+// fetched in that same order with ds_read_b64_tr_b16 (two 4-row transposed blocks).
+//
+// LDS images are [row][D] with one XOR swizzle that is conflict-free for both ds_read_b128 row reads and
+// the transposed reads (16-byte chunk c of row r stored at chunk c ^ f(r)); tiles arrive by LDS-DMA with
+// the swizzle applied on the per-lane SOURCE address (destination is lane-linear).
+#include "common.h"
+#include "../../include/orbit2_hip.h"
+
+namespace {
+
+template <int D> struct Cfg {
+  static constexpr int CPR = D / 8;            // 16-byte chunks per row
+  static constexpr int RB = D * 2;             // row bytes
+  static constexpr int RPI = 64 / CPR;         // rows per 1-KiB LDS-DMA instruction
+  static constexpr int TILE = 64 * RB;         // bytes of a 64-row tile
+  static constexpr int NDS = D / 16;           // k-steps over the head dim
+  static constexpr int NDB = D / 32;           // 32-wide blocks of the head dim
+};
+
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if (D == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+  else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+}
+
+// stage a [64 rows][D] tile; rows are tokens tok0..tok0+63 of one head: src(row) = base + row*stride
+template <int D>
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t stride, char* tile, int wave,
+                                        int lane) {
+  using C = Cfg<D>;
+  constexpr int NI = C::TILE / 1024;  // instructions per tile (16 or 8)
+#pragma unroll
+  for (int t = 0; t < NI / 4; ++t) {
+    const int i = wave * (NI / 4) + t;
+    const int row = i * C::RPI + lane / C::CPR;
+    const int cp = lane % C::CPR;
+    const int c = cp ^ swz<D>(row);
+    glds16(base + (size_t)row * stride + c * 8, tile + i * 1024);
+  }
+}
+
+// row read: 8 consecutive head-dim elements [ds*16 + 8h .. +7] of row `row`
+template <int D>
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row, int ds, int h) {
+  const int c = ds * 2 + h;
+  return *reinterpret_cast<const bf16x8*>(tile + row * Cfg<D>::RB + ((c ^ swz<D>(row)) << 4));
+}
+
+// transposed read: lane (column = db*32 + (lane&31), h = lane>>5) gets rows rbase + {4h..4h+3, 8+4h..8+4h+3}
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rbase, int db, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = lane >> 5;
+  const int row = rbase + 4 * h + q;
+  const int c = db * 4 + 2 * (g & 1) + (p >> 1);
+  const char* a0 = tile + row * Cfg<D>::RB + ((c ^ swz<D>(row)) << 4) + 8 * (p & 1);
+  const int row1 = row + 8;
+  const char* a1 = tile + row1 * Cfg<D>::RB + ((c ^ swz<D>(row1)) << 4) + 8 * (p & 1);
+  const bf16x4 lo = lds_tr4(a0), hi = lds_tr4(a1);
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(x[8 * s + j]);
+  return r;
+}
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// dropout on a 32x32 tile whose lane-local axis (registers) runs along KEYS: registers 4t..4t+3 are keys
+// kbase + 8t + 4h + {0..3} of query row qrow -> one hash per 4 registers.
+__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint64_t rowbase /* (bh*L+q)*L */,
+                                                  int kbase, int h, unsigned thr, float dscale) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint64_t idx = (rowbase + (uint64_t)(kbase + 8 * t + 4 * h)) >> 2;
+    const uint32_t hh = o2_hash64(seed, idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[4 * t + e] = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] * dscale : 0.f;
+  }
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ lse, int L, int H, float sc_log2,
+                                                          unsigned thr, float dscale, uint64_t seed) {
+  using C = Cfg<D>;
+  __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // [2 stages][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;  // MFMA half
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;  // token stride in qkv
+  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
+  const bf16_t* kbase = qbase + (size_t)H * D;
+  const bf16_t* vbase = qbase + (size_t)2 * H * D;
+  const int qrow = q0 + (lane & 31);
+
+  bf16x8 qf[C::NDS];
+#pragma unroll
+  for (int ds = 0; ds < C::NDS; ++ds)
+    qf[ds] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq);
+
+  f32x16 o[C::NDB];
+#pragma unroll
+  for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const uint64_t rowbase = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)L;
+
+  const int nt = L / 64;
+  stage64<D>(kbase, tstride, smem, wave, lane);
+  stage64<D>(vbase, tstride, smem + C::TILE, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sk = smem + cur * 2 * C::TILE;
+    const char* sv = sk + C::TILE;
+    if (t + 1 < nt) {
+      char* nk = smem + (cur ^ 1) * 2 * C::TILE;
+      stage64<D>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane);
+      stage64<D>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane);
+    }
+    // S^T[kb] = K_kb . Q^T   (rows = keys in registers, column = query on the lane)
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds)
+        s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s[kb]);
+    }
+    // online softmax over this lane's query row (its 32 keys + the partner half's 32)
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sc_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[kb][r] * sc_log2 - m_new);
+        s[kb][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    if (thr) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) drop_keys_in_regs(s[kb], seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
+    }
+    // O^T[db] += V^T . P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = pack_frag(s[kb], ss);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+          o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+  bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dd = db * 32 + 8 * g4 + 4 * hq;
+      u32x2 w;
+      w[0] = pack_bf2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
+      w[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+      *reinterpret_cast<u32x2*>(orow + dd) = w;
+    }
+}
+
+// =============================================================================================
+// delta[b,h,q] = sum_d dO*O
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int L, int H, int D) {
+  // one 16-lane group per (token, head) row of D elements
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int li = threadIdx.x & 15;
+  const int64_t nrows = (int64_t)B * L * H;
+  if (grp >= nrows) return;
+  const bf16_t* po = o + grp * D;
+  const bf16_t* pd = dout + grp * D;
+  float s = 0.f;
+  for (int c = li; c < D / 8; c += 16) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(po + c * 8);
+    const u32x4 d = *reinterpret_cast<const u32x4*>(pd + c * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      s += bf2f((bf16_t)(a[j] & 0xffff)) * bf2f((bf16_t)(d[j] & 0xffff)) +
+           bf2f((bf16_t)(a[j] >> 16)) * bf2f((bf16_t)(d[j] >> 16));
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (li == 0) {
+    const int64_t tok = grp / H;
+    const int hh = (int)(grp - tok * H);
+    const int64_t bb = tok / L;
+    const int64_t q = tok - bb * L;
+    delta[((size_t)(bb * H + hh)) * L + q] = s;
+  }
+}
+
+// =============================================================================================
+// backward, dQ: same geometry as the forward (query on the lane)
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+                                                             const bf16_t* __restrict__ dout,
+                                                             const float* __restrict__ lse,
+                                                             const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dqkv, int L, int H, float scale,
+                                                             unsigned thr, float dscale, uint64_t seed) {
+  using C = Cfg<D>;
+  __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;
+  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
+  const bf16_t* kbase = qbase + (size_t)H * D;
+  const bf16_t* vbase = qbase + (size_t)2 * H * D;
+  const int qrow = q0 + (lane & 31);
+  const float sc_log2 = scale * 1.4426950408889634f;
+
+  bf16x8 qf[C::NDS], dof[C::NDS];
+  const bf16_t* dorow = dout + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
+#pragma unroll
+  for (int ds = 0; ds < C::NDS; ++ds) {
+    qf[ds] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq);
+    dof[ds] = *reinterpret_cast<const bf16x8*>(dorow + ds * 16 + 8 * hq);
+  }
+  const size_t sidx = ((size_t)(b * H + head)) * L + qrow;
+  const float lse2 = lse[sidx] * 1.4426950408889634f;
+  const float dlt = delta[sidx];
+  const uint64_t rowbase = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)L;
+
+  f32x16 dq[C::NDB];
+#pragma unroll
+  for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  const int nt = L / 64;
+  stage64<D>(kbase, tstride, smem, wave, lane);
+  stage64<D>(vbase, tstride, smem + C::TILE, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sk = smem + cur * 2 * C::TILE;
+    const char* sv = sk + C::TILE;
+    if (t + 1 < nt) {
+      char* nk = smem + (cur ^ 1) * 2 * C::TILE;
+      stage64<D>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane);
+      stage64<D>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds) {
+        s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s);
+        dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], dp);
+      }
+      if (thr) drop_keys_in_regs(dp, seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse2);
+        s[r] = p * (dp[r] - dlt);  // dS^T
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 dsf = pack_frag(s, ss);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+          dq[db] = MFMA32(tr_frag<D>(sk, kb * 32 + ss * 16, db, lane), dsf, dq[db]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  bf16_t* drow = dqkv + ((size_t)b * L + qrow) * tstride + (size_t)head * D;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dd = db * 32 + 8 * g4 + 4 * hq;
+      u32x2 w;
+      w[0] = pack_bf2(dq[db][4 * g4] * scale, dq[db][4 * g4 + 1] * scale);
+      w[1] = pack_bf2(dq[db][4 * g4 + 2] * scale, dq[db][4 * g4 + 3] * scale);
+      *reinterpret_cast<u32x2*>(drow + dd) = w;
+    }
+}
+
+// =============================================================================================
+// backward, dK/dV: key on the lane; the workgroup owns 128 keys (32 per wave) and sweeps all queries
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
+                                                              const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale,
+                                                              unsigned thr, float dscale, uint64_t seed) {
+  using C = Cfg<D>;
+  __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // [2][Q|dO] + [2][lse2|delta]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;
+  const size_t ostride = (size_t)H * D;
+  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
+  const bf16_t* kbase = qbase + (size_t)H * D;
+  const bf16_t* vbase = qbase + (size_t)2 * H * D;
+  const bf16_t* dobase = dout + (size_t)b * L * ostride + (size_t)head * D;
+  const int krow = k0 + (lane & 31);
+  const float sc_log2 = scale * 1.4426950408889634f;
+  float* sstat = reinterpret_cast<float*>(smem + 4 * C::TILE);
+
+  bf16x8 kf[C::NDS], vf[C::NDS];
+#pragma unroll
+  for (int ds = 0; ds < C::NDS; ++ds) {
+    kf[ds] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
+    vf[ds] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
+  }
+  f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+  for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  const size_t sbase = ((size_t)(b * H + head)) * L;
+  const uint64_t bh = (uint64_t)(b * H + head);
+  const int nt = L / 64;
+  auto stage_stats = [&](int t, int buf) {
+    if (tid < 128) {
+      const int which = tid >> 6, i = tid & 63;
+      const float v = which ? delta[sbase + t * 64 + i] : lse[sbase + t * 64 + i] * 1.4426950408889634f;
+      sstat[(buf * 2 + which) * 64 + i] = v;
+    }
+  };
+  stage64<D>(qbase, tstride, smem, wave, lane);
+  stage64<D>(dobase, ostride, smem + C::TILE, wave, lane);
+  stage_stats(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sq = smem + cur * 2 * C::TILE;
+    const char* sdo = sq + C::TILE;
+    if (t + 1 < nt) {
+      char* nq = smem + (cur ^ 1) * 2 * C::TILE;
+      stage64<D>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane);
+      stage64<D>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane);
+      stage_stats(t + 1, cur ^ 1);
+    }
+    const float* s_lse = sstat + (cur * 2 + 0) * 64;
+    const float* s_dlt = sstat + (cur * 2 + 1) * 64;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      // S[q x key] = Q . K^T, dP[q x key] = dO . V^T  (rows = queries in registers, column = key on the lane)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds) {
+        s = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s);
+        dp = MFMA32(row_frag<D>(sdo, qb * 32 + (lane & 31), ds, hq), vf[ds], dp);
+      }
+      f32x16 pd;  // P after dropout (for dV)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;  // query row of register r
+        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - s_lse[ql]);
+        float dpr = dp[r];
+        float pdr = p;
+        if (thr) {
+          const uint64_t qg = (uint64_t)(t * 64 + ql);
+          const uint64_t idx = ((bh * L + qg) * (uint64_t)L + (uint64_t)krow) >> 2;
+          const uint32_t hh = o2_hash64(seed, idx);
+          const bool keep = ((hh >> (8 * (krow & 3))) & 0xffu) >= thr;
+          dpr = keep ? dpr * dscale : 0.f;
+          pdr = keep ? p * dscale : 0.f;
+        }
+        pd[r] = pdr;
+        s[r] = p * (dpr - s_dlt[ql]);  // dS
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = pack_frag(pd, ss);
+        const bf16x8 dsf = pack_frag(s, ss);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+          dv[db] = MFMA32(tr_frag<D>(sdo, qb * 32 + ss * 16, db, lane), pf, dv[db]);   // dV^T += dO^T . P
+          dk[db] = MFMA32(tr_frag<D>(sq, qb * 32 + ss * 16, db, lane), dsf, dk[db]);   // dK^T += Q^T . dS
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  bf16_t* dkrow = dqkv + ((size_t)b * L + krow) * tstride + (size_t)H * D + (size_t)head * D;
+  bf16_t* dvrow = dkrow + (size_t)H * D;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dd = db * 32 + 8 * g4 + 4 * hq;
+      u32x2 w;
+      w[0] = pack_bf2(dk[db][4 * g4] * scale, dk[db][4 * g4 + 1] * scale);
+      w[1] = pack_bf2(dk[db][4 * g4 + 2] * scale, dk[db][4 * g4 + 3] * scale);
+      *reinterpret_cast<u32x2*>(dkrow + dd) = w;
+      w[0] = pack_bf2(dv[db][4 * g4], dv[db][4 * g4 + 1]);
+      w[1] = pack_bf2(dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
+      *reinterpret_cast<u32x2*>(dvrow + dd) = w;
+    }
+}
+
+}  // namespace
+
+static int attn_check(const void* a, const void* b, int B, int L, int H, int d, float p) {
+  if (!a || !b || B <= 0 || L <= 0 || H <= 0) return O2_ERR_ARG;
+  if (d != 64 && d != 128) return O2_ERR_UNSUPPORTED;
+  if (L % 128) return O2_ERR_ARG;
+  if (p < 0.f || p >= 1.f) return O2_ERR_ARG;
+  return O2_OK;
+}
+
+extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
+                               uint64_t seed, void* stream) {
+  int rc = attn_check(qkv, out, B, L, H, d, drop_p);
+  if (rc) return rc;
+  if (!lse) return O2_ERR_ARG;
+  const float sc_log2 = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
+  const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
+  const float dscale = 256.0f / (256.0f - (float)thr);
+  dim3 grid(L / 128, H, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d == 128)
+    hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
+                       thr, dscale, seed);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
+                       thr, dscale, seed);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                               void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, void* stream) {
+  int rc = attn_check(qkv, out, B, L, H, d, drop_p);
+  if (rc) return rc;
+  if (!dout || !lse || !delta || !dqkv) return O2_ERR_ARG;
+  const float scale = 1.0f / sqrtf((float)d);
+  const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
+  const float dscale = 256.0f / (256.0f - (float)thr);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nrows = (int64_t)B * L * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, s,
+                     (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
+  O2_CHECK_LAUNCH();
+  dim3 grid(L / 128, H, B), block(256);
+  if (d == 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
+                       (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
+  }
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

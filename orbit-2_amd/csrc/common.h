@@ -1,0 +1,81 @@
+// Shared device helpers for liborbit2_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define O2_OK 0
+#define O2_ERR_ARG (-1)
+#define O2_ERR_LAUNCH (-2)
+#define O2_ERR_UNSUPPORTED (-3)
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// 16-byte LDS-DMA: every lane supplies its own global source; the LDS destination is
+// (wave-uniform base) + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(void, gsrc), LDS_PTR(void, lds_wave_base), 16, 0, 0);
+}
+// transposed 4x16 block read (ds_read_b64_tr_b16): lane i of a 16-lane group receives column i.
+__device__ __forceinline__ bf16x4 lds_tr4(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, lds_addr));
+}
+
+// ---- counter-based dropout hash ------------------------------------------------------
+// One 32-bit hash per group of 4 consecutive elements; element e of the group uses byte e.
+// keep <=> byte >= thr   (thr = round(p*256), effective drop prob thr/256, scale 256/(256-thr)).
+// tests/ replicate this function in numpy to build bit-identical masks for the oracle.
+__device__ __host__ __forceinline__ uint32_t o2_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo,
+                                                      uint32_t idx_hi) {
+  uint32_t h = idx_lo ^ seed_lo;
+  h *= 0x9E3779B1u;
+  h ^= h >> 15;
+  h += (idx_hi * 0x85EBCA77u) ^ seed_hi;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t o2_hash64(uint64_t seed, uint64_t idx) {
+  return o2_hash((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)idx, (uint32_t)(idx >> 32));
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+#define O2_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return O2_ERR_LAUNCH;            \
+  } while (0)

@@ -1,0 +1,336 @@
+// bf16 MFMA GEMM for gfx950 with a fused epilogue.  See include/orbit2_hip.h (orbit2_gemm_bf16).
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 fragments of
+// v_mfma_f32_16x16x32_bf16.  Operands are staged global->LDS by LDS-DMA (global_load_lds_dwordx4,
+// 1 KiB per wave-instruction, lane-linear destination); the bank-conflict swizzle is applied on the
+// per-lane SOURCE address and undone on the fragment read:
+//   K-contiguous operand  : LDS image [128 rows][64 k]   (128-B rows), 16-B chunk ^= row&7,
+//                           fragments by ds_read_b128.
+//   K-strided operand     : LDS image [64 k][128 cols]   (256-B rows), 32-B granule ^= (k&3)|((k>>3)&1)<<2,
+//                           fragments by 2x ds_read_b64_tr_b16 (hardware transpose).
+// The MFMA is issued with the N-side fragment as the A operand and the M-side fragment as B, so a lane
+// ends up holding 4 consecutive n of one output row m -> 8-byte bf16 (16-byte fp32) row-major stores.
+#include "common.h"
+#include "../../include/orbit2_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
+
+template <bool KC>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0,
+                                           char* tile, int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = wave * 4 + t;  // LDS-DMA instruction id, 0..15 (1 KiB each)
+    const bf16_t* src;
+    if (KC) {
+      const int row = i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (row & 7);
+      int gr = r0 + row;
+      gr = gr < rmax ? gr : rmax - 1;
+      src = G + (size_t)gr * ld + k0 + chunk * 8;
+    } else {
+      const int krow = i * 4 + (lane >> 4);
+      const int cp = lane & 15;
+      const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int chunk = ((((cp >> 1) ^ sw)) << 1) | (cp & 1);
+      int col = r0 + chunk * 8;
+      col = col <= rmax - 8 ? col : rmax - 8;
+      src = G + (size_t)(k0 + krow) * ld + col;
+    }
+    glds16(src, tile + i * 1024);
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int r0, int kk, int lane) {
+  if (KC) {
+    const int row = r0 + (lane & 15);
+    const int chunk = kk * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int krow = kk * 32 + 8 * g + q;
+    const int sw = q | ((g & 1) << 2);
+    const char* a = tile + krow * 256 + ((((r0 >> 4) ^ sw)) << 5) + 8 * pp;
+    const bf16x4 lo = lds_tr4(a);
+    const bf16x4 hi = lds_tr4(a + 4 * 256);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+struct Epi {
+  const bf16_t* bias;
+  bf16_t* save_pre;
+  const bf16_t* dgelu_pre;
+  const float* rowscale;
+  const bf16_t* residual;
+  void* C;
+  uint64_t seed;
+  int M, N, ldc, ldr, res_mod, res_first, rows_per_scale, act, out_fp32;
+  unsigned thr;
+  float dscale, beta;
+};
+
+__device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
+  if (m >= e.M || n >= e.N) return;
+  const size_t off = (size_t)m * e.ldc + n;
+  if (e.bias) {
+    const u32x2 b = *reinterpret_cast<const u32x2*>(e.bias + n);
+    v[0] += bf2f((bf16_t)(b[0] & 0xffff)); v[1] += bf2f((bf16_t)(b[0] >> 16));
+    v[2] += bf2f((bf16_t)(b[1] & 0xffff)); v[3] += bf2f((bf16_t)(b[1] >> 16));
+  }
+  if (e.save_pre) {
+    u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(e.save_pre + off) = o;
+    // the backward recomputes GELU'(pre) from the ROUNDED value: round here too so fwd == recompute
+    v[0] = bf2f((bf16_t)(o[0] & 0xffff)); v[1] = bf2f((bf16_t)(o[0] >> 16));
+    v[2] = bf2f((bf16_t)(o[1] & 0xffff)); v[3] = bf2f((bf16_t)(o[1] >> 16));
+  }
+  if (e.act == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+  }
+  float r4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e.residual) {
+    const int rm = e.res_mod > 0 ? (m % e.res_mod) : m;
+    const u32x2 rr = *reinterpret_cast<const u32x2*>(e.residual + (size_t)rm * e.ldr + n);
+    r4[0] = bf2f((bf16_t)(rr[0] & 0xffff)); r4[1] = bf2f((bf16_t)(rr[0] >> 16));
+    r4[2] = bf2f((bf16_t)(rr[1] & 0xffff)); r4[3] = bf2f((bf16_t)(rr[1] >> 16));
+    if (e.res_first) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += r4[j];
+    }
+  }
+  if (e.thr) {
+    const uint64_t idx = ((uint64_t)m * (uint64_t)e.N + (uint64_t)n) >> 2;
+    const uint32_t h = o2_hash64(e.seed, idx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (((h >> (8 * j)) & 0xffu) >= e.thr) ? v[j] * e.dscale : 0.f;
+  }
+  if (e.dgelu_pre) {
+    const u32x2 pr = *reinterpret_cast<const u32x2*>(e.dgelu_pre + off);
+    v[0] *= dgelu_f(bf2f((bf16_t)(pr[0] & 0xffff))); v[1] *= dgelu_f(bf2f((bf16_t)(pr[0] >> 16)));
+    v[2] *= dgelu_f(bf2f((bf16_t)(pr[1] & 0xffff))); v[3] *= dgelu_f(bf2f((bf16_t)(pr[1] >> 16)));
+  }
+  if (e.rowscale) {
+    const float s = e.rowscale[m / e.rows_per_scale];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= s;
+  }
+  if (e.residual && !e.res_first) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += r4[j];
+  }
+  if (e.out_fp32) {
+    float* c = reinterpret_cast<float*>(e.C) + off;
+    if (e.beta != 0.f) {
+      const f32x4 old = *reinterpret_cast<const f32x4*>(c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += e.beta * old[j];
+    }
+    *reinterpret_cast<f32x4*>(c) = v;
+  } else {
+    bf16_t* c = reinterpret_cast<bf16_t*>(e.C) + off;
+    if (e.beta != 0.f) {
+      const u32x2 old = *reinterpret_cast<const u32x2*>(c);
+      v[0] += e.beta * bf2f((bf16_t)(old[0] & 0xffff)); v[1] += e.beta * bf2f((bf16_t)(old[0] >> 16));
+      v[2] += e.beta * bf2f((bf16_t)(old[1] & 0xffff)); v[3] += e.beta * bf2f((bf16_t)(old[1] >> 16));
+    }
+    u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(c) = o;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         int M, int N, int K, int lda, int ldb, int tiles_m,
+                                                         int tiles_n, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware remap (bijective for any grid size): blocks b, b+8, .. share an XCD -> give each XCD a
+  // contiguous range of tile ids, then walk tiles in groups of 8 tile-rows so neighbours share panels.
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsz;
+  const int tn = (id % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  stage_tile<A_KC>(A, lda, m0, M, 0, smem, wave, lane);
+  stage_tile<B_KC>(B, ldb, n0, N, 0, smem + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* sa = smem + cur * 2 * TILE_BYTES;
+    char* sb = sa + TILE_BYTES;
+    if (kt + 1 < nk) {
+      char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_tile<A_KC>(A, lda, m0, M, (kt + 1) * BK, na, wave, lane);
+      stage_tile<B_KC>(B, ldb, n0, N, (kt + 1) * BK, na + TILE_BYTES, wave, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(sa, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(sb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D[i = n][j = m]: lane holds m = lane&15, n = 4*(lane>>4) + r
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      epilogue4(epi, m, n, acc[i][j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// small fp32 GEMM (table algebra; sizes ~ [115 x D] x [D x D]): 64x64 tile, 16x16 threads, 4x4 micro-tile
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                    float* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                    int ldc, int ta, int tb, float alpha, float beta) {
+  __shared__ float sA[16][64 + 1];
+  __shared__ float sB[16][64 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      int kk, mm;
+      if (ta) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }
+      const int gm = m0 + mm, gk = k0 + kk;
+      float v = 0.f;
+      if (gm < M && gk < K) v = ta ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+      sA[kk][mm] = v;
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      int kk, nn;
+      if (tb) { kk = e & 15; nn = e >> 4; } else { nn = e & 63; kk = e >> 6; }
+      const int gn = n0 + nn, gk = k0 + kk;
+      float v = 0.f;
+      if (gn < N && gk < K) v = tb ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+      sB[kk][nn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = sB[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float* c = C + (size_t)m * ldc + n;
+      *c = alpha * acc[i][j] + (beta != 0.f ? beta * *c : 0.f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int orbit2_abi_version(void) { return ORBIT2_ABI_VERSION; }
+
+extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->B || !a->C) return O2_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return O2_ERR_ARG;
+  if (a->K % BK || a->N % 8 || a->M % 8 || a->lda % 8 || a->ldb % 8 || a->ldc % 4) return O2_ERR_ARG;
+  if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
+  if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
+  if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
+  Epi e;
+  e.bias = (const bf16_t*)a->bias;
+  e.save_pre = (bf16_t*)a->save_pre;
+  e.dgelu_pre = (const bf16_t*)a->dgelu_pre;
+  e.rowscale = a->rowscale;
+  e.residual = (const bf16_t*)a->residual;
+  e.C = a->C;
+  e.seed = a->seed;
+  e.M = a->M; e.N = a->N; e.ldc = a->ldc; e.ldr = a->ldr; e.res_mod = a->res_mod; e.res_first = a->res_first;
+  e.rows_per_scale = a->rows_per_scale; e.act = a->act; e.out_fp32 = a->out_fp32;
+  e.thr = (unsigned)(a->drop_p * 256.0f + 0.5f);
+  e.dscale = 256.0f / (256.0f - (float)e.thr);
+  e.beta = a->beta;
+  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* A = (const bf16_t*)a->A;
+  const bf16_t* B = (const bf16_t*)a->B;
+  if (a->a_kc && a->b_kc)
+    hipLaunchKernelGGL((gemm128_kernel<true, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                       tiles_m, tiles_n, e);
+  else if (a->a_kc && !a->b_kc)
+    hipLaunchKernelGGL((gemm128_kernel<true, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                       tiles_m, tiles_n, e);
+  else if (!a->a_kc && a->b_kc)
+    hipLaunchKernelGGL((gemm128_kernel<false, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                       tiles_m, tiles_n, e);
+  else
+    hipLaunchKernelGGL((gemm128_kernel<false, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                       tiles_m, tiles_n, e);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                int ldc, int ta, int tb, float alpha, float beta, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return O2_ERR_ARG;
+  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+  hipLaunchKernelGGL(sgemm_kernel, grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
+                     alpha, beta);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

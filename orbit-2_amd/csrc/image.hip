@@ -1,0 +1,402 @@
+// Hi-res tail of Res_Slim_ViT (fp32, HBM-bound, tiny): unpatchify, 3x3 convs (+GELU+PixelShuffle),
+// precipitation clamp, and the fused losses (mse / bayesian_tv with latitude and variable weights).
+#include "common.h"
+#include "../../include/orbit2_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int per_block) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  return (int)g;
+}
+
+// ---- unpatchify (res_slimvit.py:167-179): pure index permutation -------------------------------
+// img[b][c][hh*p+pp][ww*p+qq] = t[b][ (((hh*wf + ww)*p + pp)*p + qq)*C + c ],  hf = h*s/p, wf = w*s/p
+template <bool BWD>
+__global__ __launch_bounds__(256) void unpatchify_kernel(bf16_t* __restrict__ t, float* __restrict__ img, int B, int C,
+                                                         int Hh, int Wh, int p) {
+  const int64_t per = (int64_t)C * Hh * Wh;
+  const int64_t n = (int64_t)B * per;
+  const int wf = Wh / p;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e / per);
+    int64_t r = e - (int64_t)b * per;
+    if (!BWD) {
+      // e enumerates img elements
+      const int c = (int)(r / ((int64_t)Hh * Wh));
+      r -= (int64_t)c * Hh * Wh;
+      const int y = (int)(r / Wh), x = (int)(r - (int64_t)y * Wh);
+      const int hh = y / p, pp = y - hh * p, ww = x / p, qq = x - ww * p;
+      const int64_t ti = ((((int64_t)hh * wf + ww) * p + pp) * p + qq) * C + c;
+      img[e] = bf2f(t[(int64_t)b * per + ti]);
+    } else {
+      // e enumerates t elements
+      const int c = (int)(r % C);
+      int64_t q = r / C;
+      const int qq = (int)(q % p); q /= p;
+      const int pp = (int)(q % p); q /= p;
+      const int ww = (int)(q % wf);
+      const int hh = (int)(q / wf);
+      t[e] = f2bf(img[(int64_t)b * per + ((int64_t)c * Hh + (hh * p + pp)) * Wh + (ww * p + qq)]);
+    }
+  }
+}
+
+// ---- 3x3 conv forward: one thread per output pixel, COB output channels per pass ---------------
+constexpr int CONV_MAXCIN = 8;
+constexpr int COB = 16;
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const float* __restrict__ in, const int* __restrict__ cidx,
+                                                          int in_ctotal, const float* __restrict__ wgt,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          float* __restrict__ pre, const float* __restrict__ addend,
+                                                          int Ha, int Wa, int B, int Cin, int Cout, int H, int W,
+                                                          int mode, int r) {
+  __shared__ float sw[COB * CONV_MAXCIN * 9 + COB];
+  const int co0 = blockIdx.y * COB;
+  const int nco = (Cout - co0) < COB ? (Cout - co0) : COB;
+  for (int e = threadIdx.x; e < nco * Cin * 9; e += 256) sw[e] = wgt[(size_t)co0 * Cin * 9 + e];
+  for (int e = threadIdx.x; e < nco; e += 256) sw[COB * CONV_MAXCIN * 9 + e] = bias[co0 + e];
+  __syncthreads();
+  const int64_t npix = (int64_t)B * H * W;
+  for (int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x; px < npix; px += (int64_t)gridDim.x * 256) {
+    const int b = (int)(px / ((int64_t)H * W));
+    const int rem = (int)(px - (int64_t)b * H * W);
+    const int y = rem / W, x = rem - y * W;
+    float nb[CONV_MAXCIN][9];
+#pragma unroll
+    for (int ci = 0; ci < CONV_MAXCIN; ++ci) {
+      if (ci < Cin) {
+        const int cs = cidx ? cidx[ci] : ci;
+        const float* pl = in + ((size_t)b * in_ctotal + cs) * H * W;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+          nb[ci][k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? pl[(size_t)yy * W + xx] : 0.f;
+        }
+      }
+    }
+    for (int co = 0; co < nco; ++co) {
+      float acc = sw[COB * CONV_MAXCIN * 9 + co];
+#pragma unroll
+      for (int ci = 0; ci < CONV_MAXCIN; ++ci) {
+        if (ci < Cin) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc = fmaf(sw[(co * Cin + ci) * 9 + k], nb[ci][k], acc);
+        }
+      }
+      const int cg = co0 + co;
+      if (mode == 0) {
+        if (addend) acc += addend[(((size_t)b * Cout + cg) * Ha + y) * Wa + x];
+        out[(((size_t)b * Cout + cg) * H + y) * W + x] = acc;
+      } else {
+        pre[(((size_t)b * Cout + cg) * H + y) * W + x] = acc;
+        const int rr = r * r;
+        const int oc = cg / rr, sub = cg - oc * rr;
+        out[(((size_t)b * (Cout / rr) + oc) * (H * r) + (y * r + sub / r)) * (size_t)(W * r) + (x * r + sub % r)] =
+            gelu_f(acc);
+      }
+    }
+  }
+}
+
+// dpre value at (b, co, y, x) for either mode
+__device__ __forceinline__ float conv_dpre(const float* __restrict__ dout, const float* __restrict__ pre, int b,
+                                           int co, int y, int x, int Cout, int H, int W, int mode, int r) {
+  if (mode == 0) return dout[(((size_t)b * Cout + co) * H + y) * W + x];
+  const int rr = r * r;
+  const int oc = co / rr, sub = co - oc * rr;
+  const float d =
+      dout[(((size_t)b * (Cout / rr) + oc) * (H * r) + (y * r + sub / r)) * (size_t)(W * r) + (x * r + sub % r)];
+  return d * dgelu_f(pre[(((size_t)b * Cout + co) * H + y) * W + x]);
+}
+
+// ---- input gradient: one thread per (b, ci, y, x) ------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(const float* __restrict__ dout,
+                                                               const float* __restrict__ pre,
+                                                               const float* __restrict__ wgt, float* __restrict__ din,
+                                                               int B, int Cin, int Cout, int H, int W, int mode,
+                                                               int r) {
+  const int64_t n = (int64_t)B * Cin * H * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    int64_t q = e;
+    const int x = (int)(q % W); q /= W;
+    const int y = (int)(q % H); q /= H;
+    const int ci = (int)(q % Cin);
+    const int b = (int)(q / Cin);
+    float acc = 0.f;
+    for (int co = 0; co < Cout; ++co) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int yy = y + 1 - k / 3, xx = x + 1 - k % 3;  // output pixel that saw (y,x) through tap k
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          acc = fmaf(conv_dpre(dout, pre, b, co, yy, xx, Cout, H, W, mode, r), wgt[((size_t)co * Cin + ci) * 9 + k],
+                     acc);
+      }
+    }
+    din[e] = acc;
+  }
+}
+
+// ---- weight / bias gradient: 16x16 pixel tile per block, one thread per (co, ci, tap) entry -------
+constexpr int TW = 16, TH = 16;
+__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __restrict__ dout,
+                                                                 const float* __restrict__ pre,
+                                                                 const float* __restrict__ in,
+                                                                 const int* __restrict__ cidx, int in_ctotal,
+                                                                 float* __restrict__ dw, float* __restrict__ dbias,
+                                                                 int B, int Cin, int Cout, int H, int W, int mode,
+                                                                 int r) {
+  __shared__ float sd[COB][TH][TW];
+  __shared__ float si[CONV_MAXCIN][TH + 2][TW + 2];
+  const int tiles_x = (W + TW - 1) / TW;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int b = blockIdx.y;
+  for (int e = threadIdx.x; e < Cin * (TH + 2) * (TW + 2); e += 256) {
+    const int ci = e / ((TH + 2) * (TW + 2));
+    const int rem = e - ci * (TH + 2) * (TW + 2);
+    const int yy = ty0 + rem / (TW + 2) - 1, xx = tx0 + rem % (TW + 2) - 1;
+    const int cs = cidx ? cidx[ci] : ci;
+    si[ci][rem / (TW + 2)][rem % (TW + 2)] =
+        (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[(((size_t)b * in_ctotal + cs) * H + yy) * W + xx] : 0.f;
+  }
+  for (int co0 = 0; co0 < Cout; co0 += COB) {
+    const int nco = (Cout - co0) < COB ? (Cout - co0) : COB;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nco * TH * TW; e += 256) {
+      const int co = e / (TH * TW);
+      const int rem = e - co * TH * TW;
+      const int y = ty0 + rem / TW, x = tx0 + rem % TW;
+      sd[co][rem / TW][rem % TW] =
+          (y < H && x < W) ? conv_dpre(dout, pre, b, co0 + co, y, x, Cout, H, W, mode, r) : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nco * Cin * 9; e += 256) {
+      const int co = e / (Cin * 9);
+      const int rem = e - co * Cin * 9;
+      const int ci = rem / 9, k = rem - ci * 9;
+      const int ky = k / 3, kx = k - ky * 3;
+      float s = 0.f;
+      for (int y = 0; y < TH; ++y)
+#pragma unroll
+        for (int x = 0; x < TW; ++x) s = fmaf(sd[co][y][x], si[ci][y + ky][x + kx], s);
+      atomicAdd(dw + ((size_t)(co0 + co) * Cin + ci) * 9 + k, s);
+    }
+    for (int co = threadIdx.x; co < nco; co += 256) {
+      float s = 0.f;
+      for (int y = 0; y < TH; ++y)
+        for (int x = 0; x < TW; ++x) s += sd[co][y][x];
+      atomicAdd(dbias + co0 + co, s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void clamp_channel_kernel(float* __restrict__ img, const float* __restrict__ ref,
+                                                            float* __restrict__ dimg, int B, int C, int HW,
+                                                            int chan) {
+  const int64_t n = (int64_t)B * HW;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e / HW);
+    const size_t off = ((size_t)b * C + chan) * HW + (e - (int64_t)b * HW);
+    if (dimg) { if (!(ref[off] > 0.f)) dimg[off] = 0.f; }
+    else img[off] = fmaxf(img[off], 0.f);
+  }
+}
+
+// ---- losses ---------------------------------------------------------------------------------------
+// err(b,c,i,j) = [(p-t)^2 + 0.02*(dv + dh + 0.7*d1 + 0.7*d2)] * latw[i] * chanw[c]     (kind 1; kind 0: no TV)
+//   dv = |p[i+1][j]-p[i][j]| (i<H-1)        dh = |p[i][j+1]-p[i][j]| (j<W-1)
+//   d1 = |p[i+1][j+1]-p[i][j]| (i<H-1,j<W-1)   d2 = |p[i+1][j-1]-p[i][j]| (i<H-1, j>=1)
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       int Ht, int Wt, const float* __restrict__ latw,
+                                                       const float* __restrict__ chanw, float* __restrict__ part,
+                                                       int C, int H, int W, int kind) {
+  const int plane = blockIdx.y;  // b*C + c
+  const int c = plane % C, b = plane / C;
+  const float* p = pred + (size_t)plane * H * W;
+  const float* t = tgt + ((size_t)b * C + c) * Ht * Wt;
+  const float cw = chanw ? chanw[c] : 1.f;
+  float s = 0.f;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
+    const int i = e / W, j = e - i * W;
+    const float pv = p[e];
+    const float d = pv - t[(size_t)i * Wt + j];
+    float err = d * d;
+    if (kind == 1) {
+      float tv = 0.f;
+      if (i < H - 1) {
+        tv += fabsf(p[e + W] - pv);
+        if (j < W - 1) tv += 0.7f * fabsf(p[e + W + 1] - pv);
+        if (j >= 1) tv += 0.7f * fabsf(p[e + W - 1] - pv);
+      }
+      if (j < W - 1) tv += fabsf(p[e + 1] - pv);
+      err += 0.02f * tv;
+    }
+    s += err * (latw ? latw[i] : 1.f) * cw;
+  }
+  s = wave_sum(s);
+  __shared__ float sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ part, int nblk, int B, int C, int HW,
+                                  float* __restrict__ out) {
+  // one wave; out[c] = mean over (b, pixels) of channel c; out[C] = mean over everything
+  float tot = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int e = threadIdx.x; e < B * nblk; e += 64) {
+      const int b = e / nblk, k = e - b * nblk;
+      s += part[((size_t)(b * C + c)) * nblk + k];
+    }
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[c] = s / ((float)B * (float)HW);
+    tot += s;
+  }
+  if (threadIdx.x == 0) out[C] = tot / ((float)B * (float)C * (float)HW);
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       int Ht, int Wt, const float* __restrict__ latw,
+                                                       const float* __restrict__ chanw,
+                                                       const float* __restrict__ gscale, float* __restrict__ dpred,
+                                                       int B, int C, int H, int W, int kind) {
+  const int64_t n = (int64_t)B * C * H * W;
+  const float g0 = gscale[0] / (float)n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    int64_t q = e;
+    const int j = (int)(q % W); q /= W;
+    const int i = (int)(q % H); q /= H;
+    const int c = (int)(q % C);
+    const int b = (int)(q / C);
+    const float* p = pred + ((size_t)b * C + c) * H * W;
+    const int o = i * W + j;
+    const float pv = p[o];
+    const float wi = latw ? latw[i] : 1.f;
+    const float wim = (latw && i > 0) ? latw[i - 1] : 1.f;
+    float g = 2.f * (pv - tgt[(((size_t)b * C + c) * Ht + i) * Wt + j]) * wi;
+    if (kind == 1) {
+      float tv = 0.f;
+      // terms stored at row i (weight wi) in which p[i][j] is the subtrahend
+      if (i < H - 1) {
+        tv -= sgn(p[o + W] - pv) * wi;
+        if (j < W - 1) tv -= 0.7f * sgn(p[o + W + 1] - pv) * wi;
+        if (j >= 1) tv -= 0.7f * sgn(p[o + W - 1] - pv) * wi;
+      }
+      if (j < W - 1) tv -= sgn(p[o + 1] - pv) * wi;
+      // terms in which p[i][j] is the minuend
+      if (j > 0) tv += sgn(pv - p[o - 1]) * wi;                              // dh stored at (i, j-1)
+      if (i > 0) {
+        tv += sgn(pv - p[o - W]) * wim;                                      // dv stored at (i-1, j)
+        if (j > 0) tv += 0.7f * sgn(pv - p[o - W - 1]) * wim;                // d1 stored at (i-1, j-1)
+        if (j < W - 1) tv += 0.7f * sgn(pv - p[o - W + 1]) * wim;            // d2 stored at (i-1, j+1)
+      }
+      g += 0.02f * tv;
+    }
+    dpred[e] = g * (chanw ? chanw[c] : 1.f) * g0;
+  }
+}
+
+}  // namespace
+
+extern "C" int orbit2_unpatchify_fwd(const void* t, float* img, int B, int C, int h, int w, int p, int s,
+                                     void* stream) {
+  if (!t || !img || B <= 0 || C <= 0 || p <= 0 || s <= 0 || (h * s) % p || (w * s) % p) return O2_ERR_ARG;
+  const int64_t n = (int64_t)B * C * h * s * w * s;
+  hipLaunchKernelGGL(unpatchify_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)t,
+                     img, B, C, h * s, w * s, p);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+extern "C" int orbit2_unpatchify_bwd(const float* dimg, void* dt, int B, int C, int h, int w, int p, int s,
+                                     void* stream) {
+  if (!dimg || !dt || B <= 0 || C <= 0 || p <= 0 || s <= 0 || (h * s) % p || (w * s) % p) return O2_ERR_ARG;
+  const int64_t n = (int64_t)B * C * h * s * w * s;
+  hipLaunchKernelGGL(unpatchify_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dt,
+                     (float*)dimg, B, C, h * s, w * s, p);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_conv3x3_fwd(const float* in, const int* chan_idx, int in_ctotal, const float* weight,
+                                  const float* bias, float* out, float* pre, const float* addend, int Ha, int Wa,
+                                  int B, int Cin, int Cout, int H, int W, int mode, int r, void* stream) {
+  if (!in || !weight || !bias || !out || B <= 0 || Cin <= 0 || Cin > CONV_MAXCIN || Cout <= 0 || H <= 0 || W <= 0)
+    return O2_ERR_ARG;
+  if (mode == 1 && (!pre || r <= 0 || Cout % (r * r))) return O2_ERR_ARG;
+  if (mode != 0 && mode != 1) return O2_ERR_ARG;
+  if (addend && (mode != 0 || Ha < H || Wa < W)) return O2_ERR_ARG;
+  dim3 grid(grid_for((int64_t)B * H * W, 256), (Cout + COB - 1) / COB);
+  hipLaunchKernelGGL(conv3x3_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, chan_idx, in_ctotal, weight,
+                     bias, out, pre, addend, Ha, Wa, B, Cin, Cout, H, W, mode, r);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_conv3x3_bwd(const float* dout, const float* in, const int* chan_idx, int in_ctotal,
+                                  const float* weight, const float* pre, float* din, float* dweight, float* dbias,
+                                  int B, int Cin, int Cout, int H, int W, int mode, int r, void* stream) {
+  if (!dout || !in || !weight || !dweight || !dbias || B <= 0 || Cin <= 0 || Cin > CONV_MAXCIN || Cout <= 0)
+    return O2_ERR_ARG;
+  if (mode == 1 && (!pre || r <= 0 || Cout % (r * r))) return O2_ERR_ARG;
+  if (mode != 0 && mode != 1) return O2_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (din) {
+    hipLaunchKernelGGL(conv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * Cin * H * W, 256)), dim3(256), 0, s, dout,
+                       pre, weight, din, B, Cin, Cout, H, W, mode, r);
+    O2_CHECK_LAUNCH();
+  }
+  dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
+  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, grid, dim3(256), 0, s, dout, pre, in, chan_idx, in_ctotal, dweight,
+                     dbias, B, Cin, Cout, H, W, mode, r);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_clamp_channel(float* img, int B, int C, int HW, int chan, void* stream) {
+  if (!img || B <= 0 || C <= 0 || HW <= 0 || chan < 0 || chan >= C) return O2_ERR_ARG;
+  hipLaunchKernelGGL(clamp_channel_kernel, dim3(grid_for((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                     img, (const float*)nullptr, (float*)nullptr, B, C, HW, chan);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+extern "C" int orbit2_clamp_channel_bwd(const float* img_clamped, float* dimg, int B, int C, int HW, int chan,
+                                        void* stream) {
+  if (!img_clamped || !dimg || B <= 0 || C <= 0 || HW <= 0 || chan < 0 || chan >= C) return O2_ERR_ARG;
+  hipLaunchKernelGGL(clamp_channel_kernel, dim3(grid_for((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (float*)nullptr, img_clamped, dimg, B, C, HW, chan);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+static const int LOSS_NBLK = 64;
+extern "C" int orbit2_loss_fwd(const float* pred, const float* target, int Ht, int Wt, const float* lat_w,
+                               const float* chan_w, float* out, float* ws, int B, int C, int H, int W, int kind,
+                               void* stream) {
+  if (!pred || !target || !out || !ws || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ht < H || Wt < W) return O2_ERR_ARG;
+  if (kind != 0 && kind != 1) return O2_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(LOSS_NBLK, B * C), dim3(256), 0, s, pred, target, Ht, Wt, lat_w, chan_w, ws,
+                     C, H, W, kind);
+  O2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, ws, LOSS_NBLK, B, C, H * W, out);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_loss_bwd(const float* pred, const float* target, int Ht, int Wt, const float* lat_w,
+                               const float* chan_w, const float* gscale, float* dpred, int B, int C, int H, int W,
+                               int kind, void* stream) {
+  if (!pred || !target || !gscale || !dpred || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ht < H || Wt < W)
+    return O2_ERR_ARG;
+  if (kind != 0 && kind != 1) return O2_ERR_ARG;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((int64_t)B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     pred, target, Ht, Wt, lat_w, chan_w, gscale, dpred, B, C, H, W, kind);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

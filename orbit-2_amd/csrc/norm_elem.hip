@@ -1,0 +1,479 @@
+// LayerNorm fwd/bwd + HBM-bound elementwise / reduction kernels (bf16 rows, 16-byte accesses).
+#include "common.h"
+#include "../../include/orbit2_hip.h"
+
+namespace {
+
+constexpr int LN_MAXD = 8192;  // up to 16 16-byte chunks per lane
+
+__device__ __forceinline__ void unpack8(const u32x4 r, float* f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f((bf16_t)(r[j] & 0xffff)); f[2 * j + 1] = bf2f((bf16_t)(r[j] >> 16)); }
+}
+
+// one wave per row; 4 rows per 256-thread block; NC = 16-byte chunks per lane (compile time)
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
+                                                     const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = D >> 3;
+  const bf16_t* xr = x + (size_t)row * D;
+  float v[NC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), v[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nch) {
+      float g[8], b[8];
+      unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), g);
+      unpack8(*reinterpret_cast<const u32x4*>(beta + ch * 8), b);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack_bf2((v[c][2 * j] - mu) * rs * g[2 * j] + b[2 * j],
+                        (v[c][2 * j + 1] - mu) * rs * g[2 * j + 1] + b[2 * j + 1]);
+      *reinterpret_cast<u32x4*>(yr + ch * 8) = o;
+    }
+  }
+}
+
+// Each wave walks LN_RPW consecutive rows (two passes per row: statistics, then dx from the L1/L2-hot
+// lines) and keeps its dgamma/dbeta partial sums in registers; one partial row per wave.
+constexpr int LN_RPW = 16;
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const bf16_t* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                     bf16_t* __restrict__ dx, float* __restrict__ part, int rows,
+                                                     int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  const int pw = blockIdx.x * 4 + wave;
+  float dg[NC][8], db[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+  for (int rr = 0; rr < LN_RPW; ++rr) {
+    const int row = pw * LN_RPW + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    const bf16_t* xr = x + (size_t)row * D;
+    const bf16_t* dyr = dy + (size_t)row * D;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nch) {
+        float xv[8], dv[8], gv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), xv);
+        unpack8(*reinterpret_cast<const u32x4*>(dyr + ch * 8), dv);
+        unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xhat = (xv[j] - mu) * rs;
+          const float g = dv[j] * gv[j];
+          s1 += g; s2 += g * xhat;
+          dg[c][j] += dv[j] * xhat; db[c][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    bf16_t* dxr = dx + (size_t)row * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nch) {
+        float xv[8], dv[8], gv[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), xv);
+        unpack8(*reinterpret_cast<const u32x4*>(dyr + ch * 8), dv);
+        unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (dv[j] * gv[j] - s1 - (xv[j] - mu) * rs * s2);
+        if (dres) {
+          float rv[8];
+          unpack8(*reinterpret_cast<const u32x4*>(dres + (size_t)row * D + ch * 8), rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += rv[j];
+        }
+        u32x4 ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = pack_bf2(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<u32x4*>(dxr + ch * 8) = ov;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nch) {
+      float* pg = part + ((size_t)pw * 2 + 0) * D + ch * 8;
+      float* pb = part + ((size_t)pw * 2 + 1) * D + ch * 8;
+      *reinterpret_cast<f32x4*>(pg) = (f32x4){dg[c][0], dg[c][1], dg[c][2], dg[c][3]};
+      *reinterpret_cast<f32x4*>(pg + 4) = (f32x4){dg[c][4], dg[c][5], dg[c][6], dg[c][7]};
+      *reinterpret_cast<f32x4*>(pb) = (f32x4){db[c][0], db[c][1], db[c][2], db[c][3]};
+      *reinterpret_cast<f32x4*>(pb + 4) = (f32x4){db[c][4], db[c][5], db[c][6], db[c][7]};
+    }
+  }
+}
+
+// out[which][col] = beta*out + sum_p part[p][which][col]
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D, void* dgamma, void* dbeta,
+                                     int fp32, float beta) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * D) return;
+  const int which = e / D, col = e - which * D;
+  float s = 0.f;
+  for (int p = 0; p < nblk; ++p) s += part[((size_t)p * 2 + which) * D + col];
+  void* dst = which ? dbeta : dgamma;
+  if (fp32) {
+    float* o = (float*)dst + col;
+    *o = s + (beta != 0.f ? beta * *o : 0.f);
+  } else {
+    bf16_t* o = (bf16_t*)dst + col;
+    *o = f2bf(s + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+  }
+}
+
+// ---- dropout backward ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dym,
+                                                          int M, int N, unsigned thr, float dscale, uint64_t seed,
+                                                          const float* __restrict__ rowscale, int rows_per_scale) {
+  const int64_t nch = (int64_t)M * N / 8;
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < nch; ch += (int64_t)gridDim.x * 256) {
+    const int64_t idx = ch * 8;
+    const int m = (int)(idx / N);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(dy + idx);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f((bf16_t)(v[j] & 0xffff)); f[2 * j + 1] = bf2f((bf16_t)(v[j] >> 16)); }
+    if (thr) {
+      const uint32_t h0 = o2_hash64(seed, (uint64_t)idx >> 2), h1 = o2_hash64(seed, ((uint64_t)idx >> 2) + 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[j] = (((h0 >> (8 * j)) & 0xffu) >= thr) ? f[j] * dscale : 0.f;
+        f[4 + j] = (((h1 >> (8 * j)) & 0xffu) >= thr) ? f[4 + j] * dscale : 0.f;
+      }
+    }
+    if (rowscale) {
+      const float s = rowscale[m / rows_per_scale];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= s;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+    *reinterpret_cast<u32x4*>(dym + idx) = o;
+  }
+}
+
+// ---- column sums: stage 1 partials [P][N], stage 2 reduce ---------------------------------------
+constexpr int CS_ROWS = 64;
+template <bool FP32>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict__ xv, int M, int N, int ldx,
+                                                          float* __restrict__ part) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * CS_ROWS;
+  const int r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  float s = 0.f;
+  if (FP32) {
+    const float* x = (const float*)xv;
+    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + col];
+  } else {
+    const bf16_t* x = (const bf16_t*)xv;
+    for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ldx + col]);
+  }
+  part[(size_t)blockIdx.y * N + col] = s;
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, int P, int N, void* out, int out_fp32,
+                                     float beta) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(size_t)p * N + col];
+  if (out_fp32) {
+    float* o = (float*)out + col;
+    *o = s + (beta != 0.f ? beta * *o : 0.f);
+  } else {
+    bf16_t* o = (bf16_t*)out + col;
+    *o = f2bf(s + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+  }
+}
+
+__global__ __launch_bounds__(256) void batch_sum_kernel(const bf16_t* __restrict__ x, void* out, int B, int64_t n,
+                                                        int out_fp32, float beta) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += bf2f(x[(size_t)b * n + i]);
+    if (out_fp32) {
+      float* o = (float*)out + i;
+      *o = s + (beta != 0.f ? beta * *o : 0.f);
+    } else {
+      bf16_t* o = (bf16_t*)out + i;
+      *o = f2bf(s + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s + i * 4);
+    u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(d + i * 4) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[n4 * 4 + threadIdx.x] = f2bf(s[n4 * 4 + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = bf2f(s[i]);
+}
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ vec,
+                                                         bf16_t* __restrict__ y, int rows, int N) {
+  const int64_t n = (int64_t)rows * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = f2bf(bf2f(a[i]) + bf2f(vec[i % N]));
+}
+
+// ---- AdamW ---------------------------------------------------------------------------------
+template <bool GFP32>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                    const void* __restrict__ gv, bf16_t* __restrict__ p16, int64_t n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float rsbc2, float gs, const float* __restrict__ found_inf) {
+  if (found_inf && *found_inf != 0.f) return;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    float g[4], pp[4], mm[4], vv[4];
+    const int cnt = (n - i) >= 4 ? 4 : (int)(n - i);
+    if (cnt == 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + i), b = *reinterpret_cast<const f32x4*>(m + i),
+                  c = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { pp[j] = a[j]; mm[j] = b[j]; vv[j] = c[j]; }
+      if (GFP32) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>((const float*)gv + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gg[j];
+      } else {
+        const u32x2 gg = *reinterpret_cast<const u32x2*>((const bf16_t*)gv + i);
+        g[0] = bf2f((bf16_t)(gg[0] & 0xffff)); g[1] = bf2f((bf16_t)(gg[0] >> 16));
+        g[2] = bf2f((bf16_t)(gg[1] & 0xffff)); g[3] = bf2f((bf16_t)(gg[1] >> 16));
+      }
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        pp[j] = p[i + j]; mm[j] = m[i + j]; vv[j] = v[i + j];
+        g[j] = GFP32 ? ((const float*)gv)[i + j] : bf2f(((const bf16_t*)gv)[i + j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < cnt) {
+        const float gj = g[j] * gs;
+        pp[j] *= (1.f - lr * wd);
+        mm[j] = b1 * mm[j] + (1.f - b1) * gj;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+        const float denom = sqrtf(vv[j]) * rsbc2 + eps;
+        pp[j] -= (lr / bc1) * (mm[j] / denom);
+      }
+    }
+    if (cnt == 4) {
+      *reinterpret_cast<f32x4*>(p + i) = (f32x4){pp[0], pp[1], pp[2], pp[3]};
+      *reinterpret_cast<f32x4*>(m + i) = (f32x4){mm[0], mm[1], mm[2], mm[3]};
+      *reinterpret_cast<f32x4*>(v + i) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+      if (p16) {
+        u32x2 o; o[0] = pack_bf2(pp[0], pp[1]); o[1] = pack_bf2(pp[2], pp[3]);
+        *reinterpret_cast<u32x2*>(p16 + i) = o;
+      }
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        p[i + j] = pp[j]; m[i + j] = mm[j]; v[i + j] = vv[j];
+        if (p16) p16[i + j] = f2bf(pp[j]);
+      }
+    }
+  }
+}
+
+template <bool GFP32>
+__global__ __launch_bounds__(256) void check_finite_kernel(const void* __restrict__ gv, int64_t n, float* found) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g = GFP32 ? ((const float*)gv)[i] : bf2f(((const bf16_t*)gv)[i]);
+    bad |= !(fabsf(g) <= 3.0e38f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *found = 1.f;
+}
+
+inline int grid_for(int64_t work_items, int per_block) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return (int)g;
+}
+
+}  // namespace
+
+#define LN_DISPATCH(NCV, CALL)            \
+  do {                                    \
+    if (NCV <= 1) { CALL(1); }            \
+    else if (NCV <= 2) { CALL(2); }       \
+    else if (NCV <= 4) { CALL(4); }       \
+    else if (NCV <= 6) { CALL(6); }       \
+    else if (NCV <= 8) { CALL(8); }       \
+    else { CALL(16); }                    \
+  } while (0)
+
+extern "C" int orbit2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                                    float* rstd, int rows, int D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXD)
+    return O2_ERR_ARG;
+  const int nc = (D / 8 + 63) / 64;
+#define CALL(N)                                                                                              \
+  hipLaunchKernelGGL(ln_fwd_kernel<N>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,              \
+                     (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd,  \
+                     rows, D, eps)
+  LN_DISPATCH(nc, CALL);
+#undef CALL
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+static inline int ln_bwd_nparts(int rows) { return ((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)) * 4; }
+extern "C" int orbit2_layernorm_bwd_ws_floats(int rows, int D) { return ln_bwd_nparts(rows) * 2 * D; }
+
+extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
+                                    const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
+                                    int grads_fp32, float beta_acc, float* ws, int ws_floats, int rows, int D,
+                                    void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws) return O2_ERR_ARG;
+  if (rows <= 0 || (D & 7) || D > LN_MAXD) return O2_ERR_ARG;
+  const int nparts = ln_bwd_nparts(rows);
+  if (ws_floats < nparts * 2 * D) return O2_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = (D / 8 + 63) / 64;
+#define CALL(N)                                                                                                  \
+  hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(nparts / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,   \
+                     (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D)
+  LN_DISPATCH(nc, CALL);
+#undef CALL
+  O2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, ws, nparts, D, dgamma, dbeta,
+                     grads_fp32, beta_acc);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_dropout_bwd(const void* dy, void* dym, int M, int N, float drop_p, uint64_t seed,
+                                  const float* rowscale, int rows_per_scale, void* stream) {
+  if (!dy || !dym || M <= 0 || N <= 0 || (N & 7) || drop_p < 0.f || drop_p >= 1.f) return O2_ERR_ARG;
+  if (rowscale && rows_per_scale <= 0) return O2_ERR_ARG;
+  const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((int64_t)M * N / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dym, M, N, thr, 256.0f / (256.0f - (float)thr), seed, rowscale,
+                     rows_per_scale);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_colsum_ws_floats(int M, int N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N; }
+
+extern "C" int orbit2_colsum(const void* x, int x_fp32, int M, int N, int ldx, void* out, int out_fp32, float beta,
+                             float* ws, int ws_floats, void* stream) {
+  if (!x || !out || !ws || M <= 0 || N <= 0) return O2_ERR_ARG;
+  const int P = (M + CS_ROWS - 1) / CS_ROWS;
+  if (ws_floats < P * N) return O2_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g1((N + 255) / 256, P);
+  if (x_fp32) hipLaunchKernelGGL(colsum_part_kernel<true>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
+  else hipLaunchKernelGGL(colsum_part_kernel<false>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
+  O2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, P, N, out, out_fp32, beta);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_batch_sum(const void* x, void* out, int B, int rows, int N, int out_fp32, float beta,
+                                void* stream) {
+  if (!x || !out || B <= 0 || rows <= 0 || N <= 0) return O2_ERR_ARG;
+  const int64_t n = (int64_t)rows * N;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     out, B, n, out_fp32, beta);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return O2_ERR_ARG;
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, n);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+extern "C" int orbit2_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0) return O2_ERR_ARG;
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     dst, n);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+extern "C" int orbit2_add_rowvec(const void* a, const void* vec, void* y, int rows, int N, void* stream) {
+  if (!a || !vec || !y || rows <= 0 || N <= 0) return O2_ERR_ARG;
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((int64_t)rows * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)vec, (bf16_t*)y, rows, N);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_adamw(float* p, float* m, float* v, const void* g, int g_fp32, void* p16, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float wd, float bc1, float bc2, float grad_scale,
+                            const float* found_inf, void* stream) {
+  if (!p || !m || !v || !g || n <= 0) return O2_ERR_ARG;
+  if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return O2_ERR_ARG;
+  if (p16 && ((uintptr_t)p16 & 7)) return O2_ERR_ARG;
+  const float rsbc2 = 1.0f / sqrtf(bc2);
+  dim3 grid(grid_for((n + 3) / 4, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_fp32)
+    hipLaunchKernelGGL(adamw_kernel<true>, grid, block, 0, s, p, m, v, g, (bf16_t*)p16, n, lr, beta1, beta2, eps, wd,
+                       bc1, rsbc2, grad_scale, found_inf);
+  else
+    hipLaunchKernelGGL(adamw_kernel<false>, grid, block, 0, s, p, m, v, g, (bf16_t*)p16, n, lr, beta1, beta2, eps, wd,
+                       bc1, rsbc2, grad_scale, found_inf);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_check_finite(const void* g, int g_fp32, int64_t n, float* found_inf, void* stream) {
+  if (!g || !found_inf || n <= 0) return O2_ERR_ARG;
+  dim3 grid(grid_for(n, 256 * 8)), block(256);
+  if (g_fp32) hipLaunchKernelGGL(check_finite_kernel<true>, grid, block, 0, (hipStream_t)stream, g, n, found_inf);
+  else hipLaunchKernelGGL(check_finite_kernel<false>, grid, block, 0, (hipStream_t)stream, g, n, found_inf);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

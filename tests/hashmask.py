@@ -1,0 +1,32 @@
+"""numpy replica of csrc/common.h:o2_hash64 -- TEST INFRASTRUCTURE: lets the oracle apply the exact dropout
+mask the HIP kernels generate (keep <=> byte >= thr, thr = round(p*256), scale 256/(256-thr))."""
+import numpy as np
+
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def o2_hash64(seed: int, idx: np.ndarray) -> np.ndarray:
+    idx = idx.astype(np.uint64)
+    seed = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+    s_lo, s_hi = seed & M32, (seed >> np.uint64(32)) & M32
+    lo, hi = idx & M32, (idx >> np.uint64(32)) & M32
+    h = (lo ^ s_lo) & M32
+    h = (h * np.uint64(0x9E3779B1)) & M32
+    h ^= h >> np.uint64(15)
+    h = (h + (((hi * np.uint64(0x85EBCA77)) & M32) ^ s_hi)) & M32
+    h = (h * np.uint64(0x85EBCA6B)) & M32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def keep_mask(seed: int, n_elems: int, p: float):
+    """mask over a flat element range [0, n_elems): element i uses byte (i & 3) of hash(i >> 2)."""
+    thr = int(p * 256.0 + 0.5)
+    if thr == 0:
+        return np.ones(n_elems, dtype=np.float32), 1.0
+    i = np.arange(n_elems, dtype=np.uint64)
+    h = o2_hash64(seed, i >> np.uint64(2))
+    byte = (h >> ((i & np.uint64(3)) * np.uint64(8))) & np.uint64(0xFF)
+    return (byte >= np.uint64(thr)).astype(np.float32), 256.0 / (256.0 - thr)

@@ -1,0 +1,335 @@
+"""GPU parity tests: every C-ABI entry point against the CPU oracle (oracle/orbit2_oracle.py, plain
+PyTorch fp32) on the same seeded inputs.  bf16 kernels are compared against the fp32 oracle evaluated on
+the bf16-rounded inputs; tolerance = normalised max error (max|a-b| / max|b|), stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orbit2_oracle as O
+from tests.hashmask import keep_mask
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from climate_learn import _hip
+    _hip.lib()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _hip
+
+
+def nerr(a, b):
+    a = a.detach().float().cpu().double()
+    b = b.detach().float().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rt(t):
+    """round-trip through bf16 (what the kernel sees), back to fp32 on CPU"""
+    return t.to(torch.bfloat16).float()
+
+
+def test_selftest_layout_maps(hip):
+    assert hip.selftest() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (136, 200, 128), (1024, 1024, 512)])
+@pytest.mark.parametrize("form", ["nt", "nn", "tn", "tt"])
+def test_gemm_forms(hip, M, N, K, form):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rt(torch.randn(M, K, generator=g))
+    B = rt(torch.randn(N, K, generator=g))
+    ref = A @ B.t()
+    a_kc = form[0] == "n"
+    b_kc = form[1] == "t"
+    Ad = bf(A if a_kc else A.t().contiguous()).cuda()
+    Bd = bf(B if b_kc else B.t().contiguous()).cuda()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(Ad, Bd, out, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc)
+    torch.cuda.synchronize()
+    assert nerr(out, ref) < 2e-5   # fp32 out: only accumulation-order differences
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(Ad, Bd, outb, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc)
+    assert nerr(outb, ref) < 6e-3  # one bf16 rounding of the result (2^-8 relative)
+
+
+def test_gemm_epilogue_full(hip):
+    M, N, K, L = 256, 192, 128, 64
+    g = torch.Generator().manual_seed(5)
+    A, W = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.2)
+    bias, res = rt(torch.randn(N, generator=g)), rt(torch.randn(L, N, generator=g))
+    rs = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 1.0 / 0.9])
+    p, seed = 0.1, 0xDEADBEEF12345
+    pre = rt(A @ W.t() + bias)
+    mask, sc = keep_mask(seed, M * N, p)
+    mask = torch.from_numpy(mask).view(M, N)
+    # order: +bias -> save_pre -> GELU -> dropout -> rowscale -> +residual(row % L)
+    ref = F.gelu(pre) * mask * sc * rs.repeat_interleave(M // 4).view(M, 1) + res.repeat(M // L, 1)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    sp = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), out, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_pre=sp, drop_p=p,
+             seed=seed, rowscale=rs.cuda(), rows_per_scale=M // 4, residual=bf(res).cuda(), ldr=N, res_mod=L)
+    assert nerr(sp, pre) < 6e-3
+    assert nerr(out, ref) < 8e-3
+    # res_first: dropout applied after the residual add (pos-embed path), beta accumulate, fp32 out
+    ref2 = (A @ W.t() + bias + res.repeat(M // L, 1)) * mask * sc
+    out2 = torch.ones(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), out2, M, N, K, K, K, N, bias=bf(bias).cuda(), drop_p=p, seed=seed,
+             residual=bf(res).cuda(), ldr=N, res_mod=L, res_first=True, beta=0.5)
+    assert nerr(out2, ref2 + 0.5) < 1e-4
+    # dgelu epilogue: out = (A x W) * mask * gelu'(pre)
+    dg = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), dg, M, N, K, K, K, N, dgelu_pre=sp, drop_p=p, seed=seed)
+    prq = sp.float().cpu().requires_grad_()
+    F.gelu(prq).sum().backward()
+    assert nerr(dg, (A @ W.t()) * mask * sc * prq.grad) < 1e-4
+
+
+def test_dropout_statistics(hip):
+    M, N = 512, 1024
+    dy = torch.ones(M, N, dtype=torch.bfloat16, device="cuda")
+    out = hip.dropout_bwd(dy, M, N, 0.1, 1234567)
+    keep = (out.float() > 0).float().mean().item()
+    assert abs(keep - (1 - 26 / 256)) < 3e-3
+    mask, sc = keep_mask(1234567, M * N, 0.1)
+    assert torch.equal((out.float().cpu() > 0).view(-1), torch.from_numpy(mask) > 0)
+
+
+def test_sgemm(hip):
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K, ta, tb) in [(115, 96, 200, 0, 0), (70, 130, 64, 1, 0), (33, 65, 100, 0, 1), (64, 64, 64, 1, 1)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g)
+        B = torch.randn((N, K) if tb else (K, N), generator=g)
+        ref = (A.t() if ta else A) @ (B.t() if tb else B)
+        out = torch.empty(M, N, device="cuda")
+        hip.sgemm(A.cuda(), B.cuda(), out, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb)
+        assert nerr(out, ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [64, 256, 1024, 3072])
+def test_layernorm(hip, D):
+    rows = 200
+    g = torch.Generator().manual_seed(D)
+    x = rt(torch.randn(rows, D, generator=g) * 2 + 0.5)
+    gam, bet = rt(1 + 0.1 * torch.randn(D, generator=g)), rt(0.1 * torch.randn(D, generator=g))
+    dy, dres = rt(torch.randn(rows, D, generator=g)), rt(torch.randn(rows, D, generator=g))
+    xr, gr, br = x.clone().requires_grad_(), gam.clone().requires_grad_(), bet.clone().requires_grad_()
+    yr = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    yr.backward(dy)
+    y, mean, rstd = hip.layernorm_fwd(bf(x).cuda(), bf(gam).cuda(), bf(bet).cuda())
+    assert nerr(y, yr) < 6e-3
+    dg = torch.empty(D, device="cuda"); db = torch.empty(D, device="cuda")
+    dx = hip.layernorm_bwd(bf(dy).cuda(), bf(x).cuda(), bf(gam).cuda(), mean, rstd, bf(dres).cuda(), dg, db)
+    assert nerr(dx, xr.grad + dres) < 8e-3
+    assert nerr(dg, gr.grad) < 1e-3 and nerr(db, br.grad) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, L, H, d, mask=None, sc=1.0):
+    q, k, v = qkv.view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    a = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    if mask is not None:
+        a = a * mask * sc
+    return (a @ v).transpose(1, 2).reshape(B, L, H * d)
+
+
+@pytest.mark.parametrize("d,H,L,B", [(64, 2, 128, 2), (128, 2, 256, 1), (64, 4, 512, 1), (128, 3, 384, 2)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_fwd_bwd(hip, d, H, L, B, p):
+    g = torch.Generator().manual_seed(d + L)
+    qkv = rt(torch.randn(B, L, 3 * H * d, generator=g)).requires_grad_()
+    do = rt(torch.randn(B, L, H * d, generator=g))
+    seed = 99887766
+    mask, sc = None, 1.0
+    if p > 0:
+        m, sc = keep_mask(seed, B * H * L * L, p)
+        mask = torch.from_numpy(m).view(B, H, L, L)
+    ref = _attn_ref(qkv, B, L, H, d, mask, sc)
+    ref.backward(do)
+    qd = bf(qkv.detach()).cuda()
+    out, lse = hip.attn_fwd(qd, B, L, H, d, p, seed)
+    assert nerr(out, ref) < 1e-2
+    q, k, _ = qkv.detach().view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1)
+    assert nerr(lse, lse_ref) < 1e-3
+    dqkv = hip.attn_bwd(qd, out, bf(do).cuda(), lse, B, L, H, d, p, seed)
+    gr = qkv.grad.view(B, L, 3, H * d)
+    dv = dqkv.view(B, L, 3, H * d)
+    for i, nm in enumerate("qkv"):
+        assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
+
+
+# ---------------------------------------------------------------------------------------------
+def _tables(sd, heads, ids, D):
+    """fp32 table algebra of the folded variable aggregation (see csrc/varagg.hip header)."""
+    dh = D // heads
+    Wq, Wkv = sd["var_agg.q.weight"], sd["var_agg.kv.weight"]
+    Wk, Wv = Wkv[:D], Wkv[D:]
+    qv = (sd["var_query"].view(1, D) @ Wq.t()).view(D)
+    U = torch.stack([(qv[h * dh:(h + 1) * dh, None] * Wk[h * dh:(h + 1) * dh]).sum(0) for h in range(heads)]) * dh ** -0.5
+    cm = []
+    for v in ids:
+        w = sd["token_embeds.%d.proj.weight" % v].view(D, 4)
+        c = sd["token_embeds.%d.proj.bias" % v] + sd["var_embed"][0, v]
+        cm.append(torch.cat([w.t(), c.view(1, D)], 0))      # [5, D]
+    cm = torch.stack(cm)                                     # [V, 5, D]
+    stab = torch.einsum("hd,vcd->hvc", U, cm)
+    gtab = torch.einsum("vcd,id->vci", cm, Wv)
+    return stab.contiguous(), gtab.contiguous()
+
+
+@pytest.mark.parametrize("D,heads,V,hw", [(64, 4, 5, (8, 16)), (256, 4, 23, (16, 32)), (384, 3, 7, (12, 20))])
+def test_varagg_fold_matches_dense_oracle(hip, D, heads, V, hw):
+    cfg = O.Config(["v%d" % i for i in range(V + 2)], hw, 1, D, 1, 1, heads)
+    sd = O.init_state_dict(cfg, V, seed=1)
+    g = torch.Generator().manual_seed(11)
+    for k in ("var_embed", "var_query"):
+        sd[k] = torch.randn(sd[k].shape, generator=g) * 0.5
+    for k in list(sd):
+        if k.startswith("var_agg") or k.startswith("token_embeds"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * (0.3 if "token" in k else 0.15)
+    ids = list(range(1, V + 1))
+    B = 2
+    x = torch.randn(B, V, *hw, generator=g)
+    leaves = {k: sd[k].clone().requires_grad_() for k in sd if k.startswith(("var_", "token_embeds"))}
+    toks = [O.patch_embed(x[:, i:i + 1], leaves["token_embeds.%d.proj.weight" % v],
+                          leaves["token_embeds.%d.proj.bias" % v], 2) for i, v in enumerate(ids)]
+    t = torch.stack(toks, 1) + leaves["var_embed"][:, ids].unsqueeze(2)
+    # dense oracle up to (but excluding) proj: use identity proj to expose z
+    eye, zero = torch.eye(D), torch.zeros(D)
+    zref = O.variable_aggregation(t, leaves["var_query"], leaves["var_agg.q.weight"], leaves["var_agg.kv.weight"],
+                                  eye, zero, heads)
+    L = zref.shape[1]
+    dz = rt(torch.randn(B * L, D, generator=g))
+    zref.reshape(B * L, D).backward(dz)
+    # folded path: tables (autograd on CPU for the reference grads of the tables), kernel on GPU
+    leaves2 = {k: sd[k].clone().requires_grad_() for k in leaves}
+    stab, gtab = _tables(leaves2, heads, ids, D)
+    z, attw = hip.varagg_fwd(x.cuda(), stab.detach().cuda(), gtab.detach().cuda(), heads, D)
+    assert nerr(z, zref.reshape(B * L, D)) < 6e-3
+    dstab, dgtab = hip.varagg_bwd(x.cuda(), gtab.detach().cuda(), attw, bf(dz).cuda(), heads, D)
+    torch.autograd.backward([stab, gtab], [dstab.cpu(), dgtab.cpu()])
+    for k in leaves:
+        if leaves[k].grad is None:
+            continue
+        assert nerr(leaves2[k].grad, leaves[k].grad) < 2e-3, k
+
+
+# ---------------------------------------------------------------------------------------------
+def test_unpatchify(hip):
+    B, C, h, w, p, s = 2, 3, 8, 16, 2, 4
+    g = torch.Generator().manual_seed(2)
+    t = rt(torch.randn(B, h * w // 4, C * 64, generator=g))
+    ref = O.unpatchify(t, (h, w), p, s, C)
+    img = hip.unpatchify_fwd(bf(t).cuda(), B, C, h, w, p, s)
+    assert torch.equal(img.cpu(), ref)
+    dimg = rt(torch.randn(ref.shape, generator=g))
+    tr = t.clone().requires_grad_()
+    O.unpatchify(tr, (h, w), p, s, C).backward(dimg)
+    dt = hip.unpatchify_bwd(dimg.cuda(), B, C, h, w, p, s)
+    assert torch.equal(dt.float().cpu(), tr.grad)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv3x3(hip, mode):
+    g = torch.Generator().manual_seed(9 + mode)
+    B, ctot, H, W = 2, 9, 12, 20
+    Cin, Cout, r = (7, 64, 4) if mode else (4, 3, 1)
+    idx = torch.tensor([8, 2, 0, 5, 4, 1, 7][:Cin], dtype=torch.int32)
+    x = torch.randn(B, ctot, H, W, generator=g)
+    wgt = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    xs = x[:, idx.long()].clone().requires_grad_()
+    y = F.conv2d(xs, wgt, b, padding=1)
+    add = None
+    if mode:
+        yr = F.pixel_shuffle(F.gelu(y), r)
+    else:
+        add = torch.randn(B, Cout, H + 3, W + 2, generator=g)
+        yr = y + add[:, :, :H, :W]
+    do = torch.randn(yr.shape, generator=g)
+    yr.backward(do)
+    out, pre = hip.conv3x3_fwd(x.cuda(), idx.cuda(), wgt.detach().cuda(), b.detach().cuda(), mode, r,
+                               None if add is None else add.cuda())
+    assert nerr(out, yr) < 1e-5
+    din, dw, db = hip.conv3x3_bwd(do.cuda(), x.cuda(), idx.cuda(), wgt.detach().cuda(), pre, True, mode, r)
+    assert nerr(din, xs.grad) < 1e-5 and nerr(dw, wgt.grad) < 1e-4 and nerr(db, b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["mse", "bayesian_tv"])
+@pytest.mark.parametrize("lat", [False, True])
+def test_loss(hip, kind, lat):
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 2, 3, 24, 40
+    pred = torch.randn(B, C, H, W, generator=g).requires_grad_()
+    tgt = torch.randn(B, C, H + 5, W + 7, generator=g)
+    names = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+    vw = {"2m_temperature_min": 10.0, "2m_temperature_max": 10.0}
+    lw = O.lat_weights(np.linspace(-80, 80, H + 5), H) if lat else None
+    full = O.LOSSES[kind](pred, O.crop_target(tgt, pred), names, vw, False, lw)
+    full[-1].backward()
+    cw = torch.tensor([1.0, 10.0, 10.0])
+    out = hip.loss_fwd(pred.detach().cuda(), tgt.cuda(), None if lw is None else lw.view(-1).cuda(), cw.cuda(),
+                       int(kind == "bayesian_tv"))
+    assert nerr(out, full) < 2e-5
+    dp = hip.loss_bwd(pred.detach().cuda(), tgt.cuda(), None if lw is None else lw.view(-1).cuda(), cw.cuda(),
+                      torch.ones(1, device="cuda"), int(kind == "bayesian_tv"))
+    assert nerr(dp, pred.grad) < 2e-5
+
+
+def test_clamp_channel(hip):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    y = hip.clamp_channel_(x.clone().cuda(), 1)
+    ref = x.clone(); ref[:, 1].clamp_(min=0)
+    assert torch.equal(y.cpu(), ref)
+    d = hip.clamp_channel_bwd_(y, torch.ones_like(y), 1)
+    refd = torch.ones_like(x); refd[:, 1] = (x[:, 1] > 0).float()
+    assert torch.equal(d.cpu(), refd)
+
+
+def test_adamw_and_casts(hip):
+    g = torch.Generator().manual_seed(6)
+    n = 10007
+    p = torch.randn(n + 1, generator=g)[:n].clone()
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step, gr in enumerate(grads, 1):
+        O.adamw_step(pr, gr, mr, vr, step, 5e-4, 0.9, 0.99, 1e-8, 1e-5)
+        hip.adamw(pd, md, vd, (gr * 4.0).cuda(), p16, n, 5e-4, 0.9, 0.99, 1e-8, 1e-5, step, grad_scale=0.25)
+    assert nerr(pd, pr) < 1e-6 and nerr(md, mr) < 1e-6 and nerr(vd, vr) < 1e-6
+    assert torch.equal(p16.cpu(), pd.cpu().to(torch.bfloat16))
+    # bf16 grads + found_inf skip
+    fi = torch.zeros(1, device="cuda")
+    gb = grads[0].to(torch.bfloat16).cuda()
+    gb[17] = float("inf")
+    hip.check_finite(gb, n, fi)
+    assert fi.item() == 1.0
+    before = pd.clone()
+    hip.adamw(pd, md, vd, gb, p16, n, 5e-4, 0.9, 0.99, 1e-8, 1e-5, 4, found_inf=fi)
+    assert torch.equal(before, pd)
+    assert torch.equal(hip.cast_to_bf16(p.cuda()).cpu(), p.to(torch.bfloat16))
+
+
+def test_colsum_batchsum(hip):
+    g = torch.Generator().manual_seed(12)
+    x = rt(torch.randn(300, 264, generator=g))
+    out = torch.empty(264, device="cuda")
+    hip.colsum(bf(x).cuda(), 300, 264, 264, out)
+    assert nerr(out, x.sum(0)) < 1e-5
+    xb = rt(torch.randn(3, 40, 64, generator=g))
+    o2 = torch.empty(40, 64, device="cuda")
+    hip.batch_sum(bf(xb).cuda(), 3, 40, 64, o2)
+    assert nerr(o2, xb.sum(0)) < 1e-6
