@@ -96,6 +96,8 @@ int orbit2_colsum(const void* x, int x_fp32, int M, int N, int ldx, void* out, i
 int orbit2_colsum_ws_floats(int M, int N);
 /* out[r][n] = sum_b x[b][r][n]  (pos_embed gradient over the batch, res_slimvit.py:273) */
 int orbit2_batch_sum(const void* x, void* out, int B, int rows, int N, int out_fp32, float beta, void* stream);
+/* DropPath (timm 0.9.2, vit_blocks.py:61,74): out[b] = 0 with prob p else 1/(1-p), from hash(seed, b) */
+int orbit2_droppath_scales(float* out, int B, float p, uint64_t seed, void* stream);
 int orbit2_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int orbit2_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* y = a + b (bf16), used for pos_embed + spatial_embed table (res_slimvit.py:273-281) */

@@ -1,0 +1,21 @@
+"""climate_learn -- MI355X-native (gfx950) build of ORBIT-2's intermediate_downscaling hot path.
+
+Mirrors the reference package surface the driver uses (`import climate_learn as cl`): the load_* factories,
+`cl.data.IterDataModule`, the model / metrics registries, `FusedAttn`.  All compute goes through
+liborbit2_hip.so (include/orbit2_hip.h); there is no CPU fallback."""
+from .utils.fused_attn import FusedAttn
+from .utils.loaders import (
+    load_model_module,
+    load_forecasting_module,
+    load_climatebench_module,
+    load_downscaling_module,
+    load_architecture,
+    load_optimizer,
+    load_lr_scheduler,
+    load_loss,
+    load_transform,
+)
+from . import data
+from .dist.dp_engine import HipDataParallel
+from .optim import HipAdamW, HipGradScaler
+from ._ops import manual_seed

@@ -329,3 +329,9 @@ def selftest(device="cuda") -> int:
     _chk(lib().orbit2_selftest(_p(buf), _stream()), "orbit2_selftest")
     torch.cuda.synchronize()
     return int(buf[0].item())
+
+
+def droppath_scales(B, p, seed, device):
+    out = torch.empty(B, dtype=F32, device=device)
+    _chk(lib().orbit2_droppath_scales(_p(out), B, C.c_float(p), C.c_uint64(seed), _stream()), "orbit2_droppath_scales")
+    return out

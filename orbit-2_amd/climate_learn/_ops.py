@@ -1,0 +1,547 @@
+"""Autograd functions that orchestrate the HIP kernels (climate_learn._hip) for the Res_Slim_ViT hot path.
+
+Each Function is one fused stage of the training step with a hand-written backward made of the same C-ABI
+kernels -- no ATen compute kernels run inside them.  Precision policy = the reference's FSDP MixedPrecision
+(examples/intermediate_downscaling.py:601-607): fp32 master parameters, bf16 compute copies and activations,
+fp32 accumulation inside the kernels, bf16 weight gradients.
+
+Parameters are passed to the Functions as the module's fp32 nn.Parameters (for graph connectivity); the kernels
+read `param._o2c` (bf16 compute copy, maintained by the DP engine / optimizer) and write weight gradients
+straight into `param._o2g` (a view of the engine's flat gradient bucket), then notify the engine so the
+bucket's RCCL all-reduce can start while backward continues.  Without an engine (unit tests) the compute
+copy is cast on the fly and gradients are returned to autograd as ordinary tensors.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _hip
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+# ------------------------------------------------------------------------------------------------------
+# dropout seed stream (counter-based: every dropout site of every step gets its own 64-bit seed)
+# ------------------------------------------------------------------------------------------------------
+class _SeedStream:
+    def __init__(self):
+        self.base = 0x243F6A8885A308D3
+        self.counter = 0
+
+    def manual_seed(self, seed: int, rank: int = 0):
+        self.base = (int(seed) * 0x9E3779B97F4A7C15 + (rank + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        self.counter = 0
+
+    def next(self) -> int:
+        self.counter += 1
+        z = (self.base + self.counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+
+seeds = _SeedStream()
+
+
+def manual_seed(seed: int, rank: int = 0):
+    seeds.manual_seed(seed, rank)
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameter plumbing
+# ------------------------------------------------------------------------------------------------------
+def cw(p: torch.Tensor) -> torch.Tensor:
+    """bf16 compute copy of a parameter."""
+    c = getattr(p, "_o2c", None)
+    if c is not None:
+        return c
+    return _hip.cast_to_bf16(p.detach().contiguous())
+
+
+class _GradSink:
+    """Where a weight gradient goes: the engine's bucket view (managed) or a fresh tensor handed to autograd."""
+    __slots__ = ("param", "buf", "beta", "managed")
+
+    def __init__(self, param: torch.Tensor, dtype=BF):
+        g = getattr(param, "_o2g", None)
+        self.param = param
+        if g is not None:
+            self.buf, self.managed = g, True
+            self.beta = 0.0 if getattr(param, "_o2_fresh", True) else 1.0
+        else:
+            self.buf = torch.empty(param.shape, dtype=dtype, device=param.device)
+            self.beta, self.managed = 0.0, False
+
+    def done(self):
+        """returns what the Function's backward must return for this parameter"""
+        if self.managed:
+            self.param._o2_fresh = False
+            eng = getattr(self.param, "_o2_engine", None)
+            if eng is not None:
+                eng.grad_ready(self.param)
+            return None
+        return self.buf
+
+
+def _needs(ctx, i):
+    return ctx.needs_input_grad[i]
+
+
+def _linear_fwd(x2d, W, b, M, N, K, **kw):
+    out = torch.empty(M, N, dtype=BF, device=x2d.device)
+    return _hip.gemm(x2d, cw(W), out, M, N, K, K, K, N, bias=None if b is None else cw(b), **kw)
+
+
+def _dx(dy2d, W, M, N, K, **kw):
+    """dx[M,K] = dy[M,N] . W[N,K]"""
+    out = torch.empty(M, K, dtype=BF, device=dy2d.device)
+    return _hip.gemm(dy2d, cw(W), out, M, K, N, N, K, K, a_kc=True, b_kc=False, **kw)
+
+
+def _dw(dy2d, x2d, W, b, M, N, K):
+    """dW[N,K] = dy^T . x ; db[N] = colsum(dy).  Returns what backward must return for (W, b)."""
+    sw = _GradSink(W)
+    _hip.gemm(dy2d, x2d, sw.buf, N, K, M, N, K, K, a_kc=False, b_kc=False, beta=sw.beta)
+    gw = sw.done()
+    gb = None
+    if b is not None:
+        sb = _GradSink(b)
+        _hip.colsum(dy2d, M, N, N, sb.buf, beta=sb.beta)
+        gb = sb.done()
+    return gw, gb
+
+
+def _ln_bwd(dy, x, gamma_p, beta_p, mean, rstd, dres):
+    sg, sb = _GradSink(gamma_p), _GradSink(beta_p)
+    assert sg.beta == sb.beta
+    dx = _hip.layernorm_bwd(dy, x, cw(gamma_p), mean, rstd, dres, sg.buf, sb.buf, beta_acc=sg.beta)
+    return dx, sg.done(), sb.done()
+
+
+def _drop_bwd(dy, M, N, p, seed, rowscale, rps):
+    if p > 0.0 or rowscale is not None:
+        return _hip.dropout_bwd(dy, M, N, p, seed, rowscale, rps)
+    return dy
+
+
+# ------------------------------------------------------------------------------------------------------
+# transformer block   (reference: components/vit_blocks.py:76-81, attention.py:43-87, mlp.py:57-73)
+# ------------------------------------------------------------------------------------------------------
+class BlockFn(torch.autograd.Function):
+    """x2 = x1 + DropPath(Mlp(LN2(x1))),  x1 = x + DropPath(Attn(LN1(x))) -- 7 kernels forward, 15 backward."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2):
+        B, L, D = x.shape
+        H = cfg["heads"]
+        d = D // H
+        M = B * L
+        hid = w1.shape[0]
+        p_attn, p_proj, p_mlp, p_path = cfg["attn_drop"], cfg["proj_drop"], cfg["mlp_drop"], cfg["drop_path"]
+        sa = seeds.next() if p_attn > 0 else 0
+        sp = seeds.next() if p_proj > 0 else 0
+        s1 = seeds.next() if p_mlp > 0 else 0
+        s2 = seeds.next() if p_mlp > 0 else 0
+        dp1 = dp2 = None
+        if p_path > 0:
+            dp1 = _hip.droppath_scales(B, p_path, seeds.next(), x.device)
+            dp2 = _hip.droppath_scales(B, p_path, seeds.next(), x.device)
+        x2d = x.reshape(M, D)
+        saved = BlockFn._run(x2d, B, L, D, H, d, M, hid, (p_attn, p_proj, p_mlp), (sa, sp, s1, s2), dp1, dp2,
+                             (n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2))
+        x2 = saved[-1]
+        ctx.meta = (B, L, D, H, d, M, hid, (p_attn, p_proj, p_mlp), (sa, sp, s1, s2), cfg.get("recompute", False))
+        ctx.params = (n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2)
+        if ctx.meta[-1]:
+            ctx.save_for_backward(x2d, dp1, dp2)
+        else:
+            ctx.save_for_backward(x2d, dp1, dp2, *saved[:-1])
+        return x2.view(B, L, D)
+
+    @staticmethod
+    def _run(x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, prm):
+        n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2 = prm
+        p_attn, p_proj, p_mlp = ps
+        sa, sp, s1, s2 = sds
+        h1, mean1, rstd1 = _hip.layernorm_fwd(x2d, cw(n1w), cw(n1b))
+        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * D, D)
+        o, lse = _hip.attn_fwd(qkv, B, L, H, d, p_attn, sa)
+        o2d = o.view(M, D)
+        x1 = _linear_fwd(o2d, wp, bp, M, D, D, drop_p=p_proj, seed=sp, rowscale=dp1, rows_per_scale=L,
+                         residual=x2d, ldr=D)
+        h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b))
+        pre = torch.empty(M, hid, dtype=BF, device=x2d.device)
+        hm = _linear_fwd(h2, w1, b1, M, hid, D, act=1, save_pre=pre, drop_p=p_mlp, seed=s1)
+        x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
+                         residual=x1, ldr=D)
+        return h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm, x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        B, L, D, H, d, M, hid, ps, sds, recompute = ctx.meta
+        p_attn, p_proj, p_mlp = ps
+        sa, sp, s1, s2 = sds
+        n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2 = ctx.params
+        if recompute:
+            x2d, dp1, dp2 = ctx.saved_tensors
+            h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm, _ = BlockFn._run(
+                x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, ctx.params)
+        else:
+            x2d, dp1, dp2, h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm = ctx.saved_tensors
+        dx2 = dx2.reshape(M, D)
+        if dx2.dtype != BF or not dx2.is_contiguous():
+            dx2 = dx2.contiguous().to(BF)
+        # ---- MLP branch
+        dym2 = _drop_bwd(dx2, M, D, p_mlp, s2, dp2, L)
+        gw2, gb2 = _dw(dym2, hm, w2, b2, M, D, hid)
+        dpre = _dx(dym2, w2, M, D, hid, drop_p=p_mlp, seed=s1, dgelu_pre=pre)
+        del hm, pre, dym2
+        gw1, gb1 = _dw(dpre, h2, w1, b1, M, hid, D)
+        dh2 = _dx(dpre, w1, M, hid, D)
+        del dpre, h2
+        dx1, gn2w, gn2b = _ln_bwd(dh2, x1, n2w, n2b, mean2, rstd2, dx2)
+        del dh2, x1
+        # ---- attention branch
+        dym1 = _drop_bwd(dx1, M, D, p_proj, sp, dp1, L)
+        gwp, gbp = _dw(dym1, o2d, wp, bp, M, D, D)
+        do = _dx(dym1, wp, M, D, D)
+        del dym1
+        dqkv = _hip.attn_bwd(qkv, o2d, do, lse, B, L, H, d, p_attn, sa)
+        del do, o2d, qkv
+        gwqkv, gbqkv = _dw(dqkv, h1, wqkv, bqkv, M, 3 * D, D)
+        dh1 = _dx(dqkv, wqkv, M, 3 * D, D)
+        del dqkv, h1
+        dx, gn1w, gn1b = _ln_bwd(dh1, x2d, n1w, n1b, mean1, rstd1, dx1)
+        return (dx.view(B, L, D), None, gn1w, gn1b, gwqkv, gbqkv, gwp, gbp, gn2w, gn2b, gw1, gb1, gw2, gb2)
+
+
+# ------------------------------------------------------------------------------------------------------
+# chain of Linear(+GELU) layers with an optional leading LayerNorm
+#   head:  LN -> (Linear -> GELU) x dd -> Linear          (res_slimvit.py:104,115-120,294,326)
+#   Mlp :  Linear -> GELU -> Dropout -> Linear -> Dropout   (mlp.py:57-73, stand-alone use)
+# ------------------------------------------------------------------------------------------------------
+class ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, *prm):
+        lead = x.shape[:-1]
+        D0 = x.shape[-1]
+        M = x.numel() // D0
+        x2d = x.reshape(M, D0)
+        has_ln = cfg["ln"]
+        p_mid, p_out = cfg.get("p_mid", 0.0), cfg.get("p_out", 0.0)
+        off = 2 if has_ln else 0
+        layers = [(prm[off + 2 * i], prm[off + 2 * i + 1]) for i in range((len(prm) - off) // 2)]
+        saved = []
+        if has_ln:
+            h, mean, rstd = _hip.layernorm_fwd(x2d, cw(prm[0]), cw(prm[1]))
+            saved += [x2d, mean, rstd]
+        else:
+            h = x2d
+        sds = []
+        for i, (W, b) in enumerate(layers):
+            N, K = W.shape
+            last = i == len(layers) - 1
+            if last:
+                s = seeds.next() if p_out > 0 else 0
+                y = _linear_fwd(h, W, b, M, N, K, drop_p=p_out, seed=s)
+                saved.append(h)
+            else:
+                s = seeds.next() if p_mid > 0 else 0
+                pre = torch.empty(M, N, dtype=BF, device=x.device)
+                y = _linear_fwd(h, W, b, M, N, K, act=1, save_pre=pre, drop_p=p_mid, seed=s)
+                saved += [h, pre]
+            sds.append(s)
+            h = y
+        ctx.meta = (M, has_ln, p_mid, p_out, sds, lead, D0)
+        ctx.prm = prm
+        ctx.save_for_backward(*saved)
+        return h.view(*lead, h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        M, has_ln, p_mid, p_out, sds, lead, D0 = ctx.meta
+        prm = ctx.prm
+        sv = list(ctx.saved_tensors)
+        off = 2 if has_ln else 0
+        layers = [(prm[off + 2 * i], prm[off + 2 * i + 1]) for i in range((len(prm) - off) // 2)]
+        if has_ln:
+            x2d, mean, rstd = sv[:3]
+            sv = sv[3:]
+        nl = len(layers)
+        dy = dy.reshape(M, dy.shape[-1])
+        if dy.dtype != BF or not dy.is_contiguous():
+            dy = dy.contiguous().to(BF)
+        g = _drop_bwd(dy, M, dy.shape[-1], p_out, sds[-1], None, 0)
+        grads = [None] * (2 * nl)
+        for i in range(nl - 1, -1, -1):
+            W, b = layers[i]
+            N, K = W.shape
+            h_in = sv[2 * i] if i < nl - 1 else sv[2 * (nl - 1)]
+            grads[2 * i], grads[2 * i + 1] = _dw(g, h_in, W, b, M, N, K)
+            if i > 0:
+                pre_prev = sv[2 * (i - 1) + 1]
+                g = _dx(g, W, M, N, K, drop_p=p_mid, seed=sds[i - 1], dgelu_pre=pre_prev)
+            elif has_ln or ctx.needs_input_grad[0]:
+                g = _dx(g, W, M, N, K)
+        out = [None, None]
+        if has_ln:
+            dx, gg, gb = _ln_bwd(g, x2d, prm[0], prm[1], mean, rstd, None)
+            out[0] = dx.view(*lead, D0)
+            out += [gg, gb]
+        else:
+            out[0] = g.view(*lead, D0) if ctx.needs_input_grad[0] else None
+        return tuple(out + grads)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = Dropout(x W^T + b) (+ residual); stand-alone Linear (Attention.qkv / .proj used outside a Block)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, p_drop, residual):
+        lead = x.shape[:-1]
+        K = x.shape[-1]
+        N = W.shape[0]
+        M = x.numel() // K
+        x2d = x.reshape(M, K)
+        s = seeds.next() if p_drop > 0 else 0
+        r2d = None if residual is None else residual.reshape(M, N)
+        y = _linear_fwd(x2d, W, b, M, N, K, drop_p=p_drop, seed=s, residual=r2d, ldr=N)
+        ctx.meta = (M, N, K, p_drop, s, lead)
+        ctx.prm = (W, b)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x2d)
+        return y.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        M, N, K, p, s, lead = ctx.meta
+        W, b = ctx.prm
+        (x2d,) = ctx.saved_tensors
+        dy2 = dy.reshape(M, N)
+        if dy2.dtype != BF or not dy2.is_contiguous():
+            dy2 = dy2.contiguous().to(BF)
+        g = _drop_bwd(dy2, M, N, p, s, None, 0)
+        gw, gb = _dw(g, x2d, W, b, M, N, K)
+        dx = _dx(g, W, M, N, K).view(*lead, K) if ctx.needs_input_grad[0] else None
+        return dx, gw, gb, None, (dy if ctx.has_res else None)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        D = x.shape[-1]
+        x2d = x.reshape(-1, D)
+        y, mean, rstd = _hip.layernorm_fwd(x2d, cw(w), cw(b))
+        ctx.prm = (w, b)
+        ctx.save_for_backward(x2d, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(x2d.shape).contiguous().to(BF)
+        dx, gg, gb = _ln_bwd(dy2, x2d, ctx.prm[0], ctx.prm[1], mean, rstd, None)
+        return dx.view(dy.shape), gg, gb
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v on the packed qkv activation [B, L, 3*H*d] (attention.py:50-78)."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, p_drop):
+        B, L, C3 = qkv.shape
+        d = C3 // (3 * H)
+        s = seeds.next() if p_drop > 0 else 0
+        q = qkv.contiguous()
+        o, lse = _hip.attn_fwd(q, B, L, H, d, p_drop, s)
+        ctx.meta = (B, L, H, d, p_drop, s)
+        ctx.save_for_backward(q, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        B, L, H, d, p, s = ctx.meta
+        q, o, lse = ctx.saved_tensors
+        dq = _hip.attn_bwd(q, o, do.contiguous().to(BF), lse, B, L, H, d, p, s)
+        return dq, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# small fp32 GEMM with autograd (parameter-table algebra)
+# ------------------------------------------------------------------------------------------------------
+class SgemmFn(torch.autograd.Function):
+    """C = op(A) op(B), fp32, op = transpose if flagged."""
+
+    @staticmethod
+    def forward(ctx, A, B, ta, tb):
+        A, B = A.contiguous(), B.contiguous()
+        M = A.shape[1] if ta else A.shape[0]
+        K = A.shape[0] if ta else A.shape[1]
+        N = B.shape[0] if tb else B.shape[1]
+        out = torch.empty(M, N, dtype=F32, device=A.device)
+        _hip.sgemm(A, B, out, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb)
+        ctx.meta = (ta, tb, M, N, K)
+        ctx.save_for_backward(A, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, dC):
+        ta, tb, M, N, K = ctx.meta
+        A, B = ctx.saved_tensors
+        dC = dC.contiguous()
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty_like(A)
+            if not ta:   # dA[M,K] = dC[M,N] . op(B)^T ; op(B)[K,N]
+                _hip.sgemm(dC, B, dA, M, K, N, N, B.shape[1], K, ta=False, tb=not tb)
+            else:        # A stored [K,M]: dA[K,M] = op(B)[K,N] . dC^T[N,M]
+                _hip.sgemm(B, dC, dA, K, M, N, B.shape[1], N, M, ta=tb, tb=True)
+        if ctx.needs_input_grad[1]:
+            dB = torch.empty_like(B)
+            if not tb:   # B stored [K,N]: dB = op(A)^T[K,M] . dC[M,N]
+                _hip.sgemm(A, dC, dB, K, N, M, A.shape[1], N, N, ta=not ta, tb=False)
+            else:        # B stored [N,K]: dB[N,K] = dC^T[N,M] . op(A)[M,K]
+                _hip.sgemm(dC, A, dB, N, K, M, N, A.shape[1], K, ta=True, tb=ta)
+        return dA, dB, None, None
+
+
+def sgemm(A, B, ta=False, tb=False):
+    return SgemmFn.apply(A, B, ta, tb)
+
+
+# ------------------------------------------------------------------------------------------------------
+# embedding front-end: folded patch-embed + variable aggregation + proj + pos/res embedding + dropout
+#   (res_slimvit.py:250-284, attention.py:132-183, patch_embed.py:44-52)
+# ------------------------------------------------------------------------------------------------------
+class EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xgrid, stab, gtab, posres, wp, bp, H, p_drop):
+        B, V, h, w = xgrid.shape
+        D = wp.shape[0]
+        L = (h // 2) * (w // 2)
+        M = B * L
+        xg = xgrid.contiguous()
+        if xg.dtype != F32:
+            xg = xg.float()
+        st, gt = stab.contiguous(), gtab.contiguous()
+        z, attw = _hip.varagg_fwd(xg, st, gt, H, D)
+        pr16 = _hip.cast_to_bf16(posres.contiguous())
+        s = seeds.next() if p_drop > 0 else 0
+        tok = _linear_fwd(z, wp, bp, M, D, D, drop_p=p_drop, seed=s, residual=pr16, ldr=D, res_mod=L,
+                          res_first=True)
+        ctx.meta = (B, V, h, w, H, D, L, M, p_drop, s)
+        ctx.prm = (wp, bp)
+        ctx.save_for_backward(xg, gt, attw, z)
+        return tok.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        B, V, h, w, H, D, L, M, p, s = ctx.meta
+        wp, bp = ctx.prm
+        xg, gt, attw, z = ctx.saved_tensors
+        d2 = dtok.reshape(M, D)
+        if d2.dtype != BF or not d2.is_contiguous():
+            d2 = d2.contiguous().to(BF)
+        g = _drop_bwd(d2, M, D, p, s, None, 0)
+        dposres = None
+        if ctx.needs_input_grad[3]:
+            dposres = torch.empty(L, D, dtype=F32, device=g.device)
+            _hip.batch_sum(g, B, L, D, dposres)
+        gwp, gbp = _dw(g, z, wp, bp, M, D, D)
+        dz = _dx(g, wp, M, D, D)
+        dstab, dgtab = _hip.varagg_bwd(xg, gt, attw, dz, H, D)
+        return None, dstab, dgtab, dposres, gwp, gbp, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# hi-res tail
+# ------------------------------------------------------------------------------------------------------
+class UnpatchifyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, C, h, w, p, s):
+        B = t.shape[0]
+        ctx.meta = (B, C, h, w, p, s)
+        return _hip.unpatchify_fwd(t.contiguous(), B, C, h, w, p, s)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        B, C, h, w, p, s = ctx.meta
+        return _hip.unpatchify_bwd(dimg.contiguous(), B, C, h, w, p, s), None, None, None, None, None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """3x3 conv (pad 1) on fp32 NCHW with optional channel gather, GELU+PixelShuffle epilogue, image addend."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chan_idx, mode, r, addend):
+        x = x.contiguous()
+        if x.dtype != F32:
+            x = x.float()
+        wd, bd = weight.detach().contiguous(), bias.detach().contiguous()
+        out, pre = _hip.conv3x3_fwd(x, chan_idx, wd, bd, mode, r, None if addend is None else addend.contiguous())
+        ctx.meta = (mode, r, None if addend is None else tuple(addend.shape))
+        ctx.idx = chan_idx
+        ctx.save_for_backward(x, wd, pre if pre is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mode, r, ashape = ctx.meta
+        x, wd, pre = ctx.saved_tensors
+        dout = dout.contiguous()
+        din, dw, db = _hip.conv3x3_bwd(dout, x, ctx.idx, wd, pre if mode == 1 else None, ctx.needs_input_grad[0],
+                                       mode, r)
+        dadd = None
+        if ashape is not None and ctx.needs_input_grad[6]:
+            if ashape == tuple(dout.shape):
+                dadd = dout
+            else:
+                dadd = dout.new_zeros(ashape)
+                dadd[:, :, : dout.shape[2], : dout.shape[3]] = dout
+        return din, dw, db, None, None, None, dadd
+
+
+class ClampChannelFn(torch.autograd.Function):
+    """in-place clamp of one channel at 0 (examples/intermediate_downscaling.py:267-272)."""
+
+    @staticmethod
+    def forward(ctx, img, chan):
+        ctx.chan = chan
+        ctx.mark_dirty(img)
+        _hip.clamp_channel_(img, chan)
+        ctx.save_for_backward(img)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        (img,) = ctx.saved_tensors
+        g = g.contiguous().clone()
+        _hip.clamp_channel_bwd_(img, g, ctx.chan)
+        return g, None
+
+
+class LossFn(torch.autograd.Function):
+    """fused mse / bayesian_tv (+lat / variable weights). Returns [C+1] (per-channel means, aggregate)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, lat_w, chan_w, kind):
+        pred = pred.contiguous()
+        if pred.dtype != F32:
+            pred = pred.float()
+        target = target.contiguous()
+        out = _hip.loss_fwd(pred, target, lat_w, chan_w, kind)
+        ctx.kind = kind
+        ctx.save_for_backward(pred, target, lat_w if lat_w is not None else pred.new_empty(0),
+                              chan_w if chan_w is not None else pred.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, lat_w, chan_w = ctx.saved_tensors
+        gs = g[-1:].contiguous().float()          # gradient flows through the aggregate entry only
+        dp = _hip.loss_bwd(pred, target, lat_w if lat_w.numel() else None, chan_w if chan_w.numel() else None, gs,
+                           ctx.kind)
+        return dp, None, None, None, None

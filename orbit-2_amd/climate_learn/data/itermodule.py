@@ -1,0 +1,101 @@
+"""Synthetic stand-in for the reference's IterDataModule (data/itermodule.py:29-231,385-469): same constructor
+keywords and accessor surface, yielding seeded synthetic (x, y, in_variables, out_variables) batches of the
+configured grid sizes.  The npz shard reader / tiling / normalisation data plane is SURVEY 8(f)-1 (next).
+
+Rank sharding follows the reference's intent (iterdataset.py:68-88: each data-parallel rank reads its own
+files): rank r draws from seed base + r."""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+_CONST = ("land_sea_mask", "orography", "lattitude", "landcover")
+
+
+class SyntheticGridDataModule:
+    def __init__(self, in_vars: Sequence[str], out_vars: Sequence[str], lowres_hw, highres_hw, batch_size=2,
+                 steps_per_epoch=4, seed=0, rank=0, device="cpu"):
+        self.in_vars, self.out_vars = list(in_vars), list(out_vars)
+        self.lo, self.hi = tuple(lowres_hw), tuple(highres_hw)
+        self.batch_size, self.steps = batch_size, steps_per_epoch
+        self.seed, self.rank = seed, rank
+        self.device = device
+        self._ready = False
+
+    # ---- reference surface ----------------------------------------------------------------------------
+    def to(self, device):
+        self.device = device
+        return self
+
+    def setup(self, stage=None):
+        self.lat = np.linspace(-90.0, 90.0, self.hi[0])
+        self.lon = np.linspace(0.0, 360.0, self.hi[1], endpoint=False)
+        g = torch.Generator().manual_seed(self.seed)          # constants are identical on every rank
+        self._consts = {v: torch.randn(self.lo, generator=g) for v in _CONST if v in self.in_vars}
+        self._ready = True
+
+    def get_lat_lon(self):
+        return (self.lat, self.lon) if self._ready else (None, None)
+
+    def get_data_dims(self):
+        return (torch.Size([self.batch_size, len(self.in_vars), *self.lo]),
+                torch.Size([self.batch_size, len(self.out_vars), *self.hi]))
+
+    def get_data_variables(self):
+        return self.in_vars, self.out_vars
+
+    def get_climatology(self, split="val"):
+        return {v: torch.zeros(self.hi) for v in self.out_vars}
+
+    def get_out_transforms(self):
+        return {v: SimpleNamespace(mean=0.0, std=1.0) for v in self.out_vars}
+
+    def _batch(self, g):
+        B = self.batch_size
+        x = torch.randn(B, len(self.in_vars), *self.lo, generator=g)
+        for i, v in enumerate(self.in_vars):
+            if v in self._consts:
+                x[:, i] = self._consts[v]
+        y = torch.randn(B, len(self.out_vars), *self.hi, generator=g)
+        if "total_precipitation_24hr" in self.out_vars:
+            i = self.out_vars.index("total_precipitation_24hr")
+            y[:, i] = torch.log1p(torch.relu(y[:, i]))
+        return x, y, self.in_vars, self.out_vars
+
+    def train_dataloader(self):
+        if not self._ready:
+            raise RuntimeError("Data module has not been set up yet.")
+        g = torch.Generator().manual_seed(self.seed * 7919 + 1 + self.rank)
+        return [self._batch(g) for _ in range(self.steps)]
+
+    def val_dataloader(self):
+        g = torch.Generator().manual_seed(self.seed * 7919 + 500009 + self.rank)
+        return [self._batch(g) for _ in range(1)]
+
+    test_dataloader = val_dataloader
+
+
+class IterDataModule(SyntheticGridDataModule):
+    """Reference keyword surface (itermodule.py:33-56).  *_dir arguments name datasets that do not exist in
+    this environment; `lowres_hw` / `highres_hw` (or the defaults of the named resolution) size the synthetic
+    grids instead."""
+
+    def __init__(self, task="downscaling", inp_root_dir=None, out_root_dir=None, in_vars=None, out_vars=None,
+                 data_par_size=1, data_par_group=None, src=None, history=1, window=6, pred_range=6, subsample=1,
+                 batch_size=64, buffer_size=10000, num_workers=0, pin_memory=False, div=1, overlap=0,
+                 lowres_hw=(32, 64), highres_hw=None, steps_per_epoch=4, seed=0):
+        if task != "downscaling":
+            raise NotImplementedError("only the downscaling task is on the hot path")
+        rank = 0
+        if data_par_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            rank = torch.distributed.get_rank(group=data_par_group)
+        if div > 1:   # spatial tiling: every sample is a 1/div x 1/div tile (+ overlap halo), iterdataset.py:112-170
+            lowres_hw = (lowres_hw[0] // div + 2 * (overlap // 2), lowres_hw[1] // div + 2 * overlap)
+            lowres_hw = (lowres_hw[0] // 2 * 2, lowres_hw[1] // 2 * 2)
+            highres_hw = None
+        highres_hw = highres_hw or (lowres_hw[0] * 4, lowres_hw[1] * 4)
+        super().__init__(in_vars, out_vars or in_vars, lowres_hw, highres_hw, batch_size, steps_per_epoch, seed, rank)

@@ -1,0 +1,225 @@
+"""Data-parallel engine for the HIP training path: the MI355X counterpart of the reference's
+FSDP(NO_SHARD) + MixedPrecision(bf16) wrap (examples/intermediate_downscaling.py:583-621).
+
+One process per GPU.  Parameters are re-homed into flat buffers, grouped into the same units FSDP's
+transformer_auto_wrap_policy({Block, Sequential}) would make (one per Block, one per Sequential, one root):
+
+    flat32  fp32 master copy of every parameter (param.data becomes a view -> state_dict stays fp32)
+    flat16  bf16 compute copy of the GEMM / LayerNorm parameters       (param._o2c)
+    g16     bf16 gradient bucket of those parameters, written by the backward kernels (param._o2g)
+    g32     fp32 gradient bucket of the remaining (fp32-compute) parameters (param.grad views)
+
+As soon as every parameter of a unit has its gradient (the backward kernels call grad_ready), the unit's
+bucket is all-reduced on a dedicated HIP stream (RCCL over xGMI; `gloo` in CPU tests), ordered after the
+compute stream by an event, so communication overlaps the rest of backward.  The sum is divided by the
+world size inside the fused AdamW (grad_scale), as FSDP's NO_SHARD gradient averaging does.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+BF, F32 = torch.bfloat16, torch.float32
+_ALIGN = 128  # elements; keeps every view 256-byte aligned
+
+
+def _round_up(n, a=_ALIGN):
+    return (n + a - 1) // a * a
+
+
+def default_units(module: nn.Module, unit_types: Tuple[type, ...]) -> List[Tuple[str, List[Tuple[str, nn.Parameter]]]]:
+    """[(unit name, [(param name, param)])]: one unit per instance of unit_types, the rest in 'root'."""
+    claimed = set()
+    units = []
+    for name, sub in module.named_modules():
+        if name and isinstance(sub, unit_types):
+            ps = [(name + "." + n, p) for n, p in sub.named_parameters() if id(p) not in claimed]
+            if ps:
+                for _, p in ps:
+                    claimed.add(id(p))
+                units.append((name, ps))
+    root = [(n, p) for n, p in module.named_parameters() if id(p) not in claimed]
+    if root:
+        units.append(("root", root))
+    return units
+
+
+class Bucket:
+    def __init__(self, name):
+        self.name = name
+        self.params: List[nn.Parameter] = []
+        self.grad_views: List[torch.Tensor] = []   # contiguous ranges to all-reduce (bf16 and/or fp32)
+        self.pending = 0
+        self.handle = None
+        self.event = None
+
+
+class HipDataParallel(nn.Module):
+    def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (),
+                 is_lowp=None, sync_module_states: bool = True, overlap: bool = True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        params = [p for p in module.parameters()]
+        assert params, "module has no parameters"
+        dev = params[0].device
+        self.device = dev
+        if is_lowp is None:
+            is_lowp = lambda name, p: getattr(p, "_o2_lowp", False)
+        units = default_units(module, unit_types)
+        # ---- layout
+        n32 = n16 = ng32 = 0
+        plan = []
+        for uname, ps in units:
+            lo = [(n, p) for n, p in ps if is_lowp(n, p)]
+            hi = [(n, p) for n, p in ps if not is_lowp(n, p)]
+            plan.append((uname, lo, hi))
+            for _, p in ps:
+                n32 += _round_up(p.numel())
+            for _, p in lo:
+                n16 += _round_up(p.numel())
+            for _, p in hi:
+                ng32 += _round_up(p.numel())
+        self.flat32 = torch.zeros(n32, dtype=F32, device=dev)
+        self.flat16 = torch.zeros(max(n16, 1), dtype=BF, device=dev)
+        self.g16 = torch.zeros(max(n16, 1), dtype=BF, device=dev)
+        self.g32 = torch.zeros(max(ng32, 1), dtype=F32, device=dev)
+        # master layout: per unit [lowp params..., fp32-compute params...]; lowp masters of ALL units are also
+        # laid out so that flat16/g16 offsets follow the same order -> AdamW runs on (few) long ranges.
+        self.buckets: List[Bucket] = []
+        self.lowp_ranges: List[Tuple[int, int, int]] = []   # (off32, off16, n) per unit
+        self.hi_ranges: List[Tuple[int, int, int]] = []     # (off32, offg32, n) per unit
+        o32 = o16 = og32 = 0
+        self._bucket_of: Dict[int, Bucket] = {}
+        for uname, lo, hi in plan:
+            bk = Bucket(uname)
+            s32, s16 = o32, o16
+            for n, p in lo:
+                k = p.numel()
+                self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
+                p.data = self.flat32[o32:o32 + k].view(p.shape)
+                p._o2c = self.flat16[o16:o16 + k].view(p.shape)
+                p._o2g = self.g16[o16:o16 + k].view(p.shape)
+                p._o2_fresh = True
+                p._o2_engine = self
+                bk.params.append(p)
+                self._bucket_of[id(p)] = bk
+                o32 += _round_up(k)
+                o16 += _round_up(k)
+            if lo:
+                self.lowp_ranges.append((s32, s16, o16 - s16))
+                bk.grad_views.append(self.g16[s16:o16])
+            s32h, sg = o32, og32
+            for n, p in hi:
+                k = p.numel()
+                self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
+                p.data = self.flat32[o32:o32 + k].view(p.shape)
+                p.grad = self.g32[og32:og32 + k].view(p.shape)
+                if p.requires_grad:
+                    bk.params.append(p)
+                    self._bucket_of[id(p)] = bk
+                    p.register_post_accumulate_grad_hook(self._hi_hook)
+                o32 += _round_up(k)
+                og32 += _round_up(k)
+            if hi:
+                self.hi_ranges.append((s32h, sg, og32 - sg))
+                bk.grad_views.append(self.g32[sg:og32])
+            self.buckets.append(bk)
+        self.refresh_compute_copies()
+        if sync_module_states and self.world > 1:
+            dist.broadcast(self.flat32, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0,
+                           group=self.pg)
+            self.refresh_compute_copies()
+        self.comm_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
+        self._launched: List[Bucket] = []
+        self.zero_grad()
+
+    # ---- parameters <-> compute copies --------------------------------------------------------------
+    def refresh_compute_copies(self):
+        """flat16 <- bf16(flat32) for every low-precision range (after init / checkpoint load)."""
+        for o32, o16, n in self.lowp_ranges:
+            if self.flat32.is_cuda:
+                from .. import _hip
+                _hip.cast_to_bf16(self.flat32[o32:o32 + n], self.flat16[o16:o16 + n])
+            else:
+                self.flat16[o16:o16 + n].copy_(self.flat32[o32:o32 + n])
+
+    # ---- gradient life cycle ------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        """Logical zero: bf16 buckets are overwritten (beta = 0) by the first backward kernel that touches
+        them; the fp32 bucket is accumulated into by autograd, so it is memset."""
+        self.g32.zero_()
+        for bk in self.buckets:
+            bk.pending = sum(1 for p in bk.params if p.requires_grad)
+            bk.handle = None
+            for p in bk.params:
+                if hasattr(p, "_o2g"):
+                    p._o2_fresh = True
+        self._launched = []
+
+    def _hi_hook(self, p):
+        self.grad_ready(p)
+
+    def grad_ready(self, p):
+        bk = self._bucket_of.get(id(p))
+        if bk is None:
+            return
+        bk.pending -= 1
+        if bk.pending == 0:
+            self._launch(bk)
+
+    def _launch(self, bk: Bucket):
+        self._launched.append(bk)
+        if self.world == 1:
+            return
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                bk.handle = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                             for v in bk.grad_views]
+        else:
+            bk.handle = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                         for v in bk.grad_views]
+
+    def finish_grad_sync(self):
+        """Block the compute stream until every launched all-reduce is done; reduce stragglers (units whose
+        parameters did not all receive a gradient this step)."""
+        for bk in self.buckets:
+            if bk not in self._launched and bk.pending != sum(1 for p in bk.params if p.requires_grad):
+                self._launch(bk)      # partially-ready unit: reduce what is there
+            elif bk not in self._launched and self.world > 1:
+                self._launch(bk)      # untouched unit still has to take part in the collective
+        for bk in self._launched:
+            if bk.handle:
+                for h in bk.handle:
+                    h.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    # ---- nn.Module surface -----------------------------------------------------------------------------
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def data_config(self, *a, **k):
+        return self.module.data_config(*a, **k)
+
+    def state_dict(self, *a, **k):
+        return self.module.state_dict(*a, **k)
+
+    def load_state_dict(self, sd, *a, **k):
+        r = self.module.load_state_dict(sd, *a, **k)
+        self.refresh_compute_copies()
+        return r
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.module, name)

@@ -1,0 +1,189 @@
+"""Res_Slim_ViT on MI355X (reference: models/hub/res_slimvit.py).
+
+Same constructor, attributes, forward signature, `data_config` and `state_dict` keys as the reference; the
+compute is the hand-written HIP path:
+
+    residual branch : 3x3 conv (+GELU+PixelShuffle fused) -> 3x3 conv                     (csrc/image.hip)
+    front-end       : folded patch-embed + variable aggregation -> proj GEMM whose epilogue adds
+                      pos+resolution embedding and applies pos_drop                         (csrc/varagg.hip, gemm.hip)
+    encoder         : depth x Block (one fused autograd node each)                        (gemm/attn/norm_elem.hip)
+    head            : final LN + decoder_depth x (Linear+GELU) + Linear                    (one autograd node)
+    tail            : unpatchify -> 3x3 conv with the residual branch added in its epilogue
+
+There is no CPU / eager fallback: inputs must live on a gfx950 device.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _ops
+from ...utils.fused_attn import FusedAttn
+from .components.attention import VariableMapping_Attention
+from .components.mlp import HipLinear
+from .components.patch_embed import PatchEmbed, _ConvParams
+from .components.pos_embed import get_2d_sincos_pos_embed, interpolate_pos_embed_on_the_fly
+from .components.vit_blocks import Block, HipLayerNorm
+from .utils import register
+
+_CONSTS = ("land_sea_mask", "orography", "lattitude", "landcover")
+
+
+class _Gelu(nn.Module):
+    """placeholder keeping nn.Sequential indices (`head.0, head.2, ...`, `path2.0, path2.3`) identical to the
+    reference's Sequential(Linear, GELU, ...) layout; the activation itself is fused into the kernels."""
+
+    def forward(self, x):  # pragma: no cover - never called on the fused path
+        raise RuntimeError("fused in the producing kernel")
+
+
+class _PixelShuffle(_Gelu):
+    pass
+
+
+@register("res_slimvit")
+class Res_Slim_ViT(nn.Module):
+    def __init__(self, default_vars, img_size, in_channels, out_channels, history, superres_mag=4, cnn_ratio=4,
+                 patch_size=16, drop_path=0.1, drop_rate=0.1, learn_pos_emb=False, embed_dim=1024, depth=24,
+                 decoder_depth=8, num_heads=16, mlp_ratio=4.0, tensor_par_size=1, tensor_par_group=None,
+                 FusedAttn_option=FusedAttn.HIP):
+        super().__init__()
+        if tensor_par_size != 1 or tensor_par_group is not None:
+            raise NotImplementedError("tensor_par_size must be 1: the build covers the data-parallel path only")
+        if patch_size != 2:
+            raise NotImplementedError("the folded patch-embed kernel implements patch_size=2 (all interm_* configs)")
+        self.default_vars = list(default_vars)
+        self.img_size = tuple(img_size)
+        self.cnn_ratio, self.superres_mag = cnn_ratio, superres_mag
+        self.in_channels = in_channels * history
+        self.out_channels = out_channels
+        self.patch_size, self.history, self.embed_dim = patch_size, history, embed_dim
+        self.num_heads, self.decoder_depth = num_heads, decoder_depth
+        self.spatial_resolution = 0
+        self.tensor_par_size, self.tensor_par_group = 1, None
+        D = embed_dim
+
+        self.spatial_embed = HipLinear(1, D)
+        self.token_embeds = nn.ModuleList([PatchEmbed(img_size, patch_size, 1, D) for _ in self.default_vars])
+        self.num_patches = self.token_embeds[0].num_patches
+        self.var_map = {v: i for i, v in enumerate(self.default_vars)}
+        self.var_embed = nn.Parameter(torch.zeros(1, len(self.default_vars), D))
+        self.var_query = nn.Parameter(torch.zeros(1, 1, D))
+        self.var_agg = VariableMapping_Attention(D, fused_attn=FusedAttn_option, num_heads=num_heads, qkv_bias=False)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, D), requires_grad=learn_pos_emb)
+        self.pos_drop_p = float(drop_rate)
+        rates = torch.linspace(0, drop_path, depth).tolist()
+        self.blocks = nn.ModuleList([
+            Block(D, num_heads=num_heads, fused_attn=FusedAttn_option, mlp_ratio=mlp_ratio, qkv_bias=True,
+                  drop_path=rates[i], proj_drop=drop_rate, attn_drop=drop_rate) for i in range(depth)])
+        self.norm = HipLayerNorm(D)
+
+        s = superres_mag
+        self.path2 = nn.Sequential(_ConvParams(out_channels + 4, cnn_ratio * s * s, 3), _Gelu(), _PixelShuffle(),
+                                   _ConvParams(cnn_ratio, out_channels, 3))
+        head: List[nn.Module] = []
+        for _ in range(decoder_depth):
+            head += [HipLinear(D, D), _Gelu()]
+        head.append(HipLinear(D, out_channels * (s * patch_size) ** 2))
+        self.head = nn.Sequential(*head)
+        self.conv_out = _ConvParams(out_channels, out_channels, 3)
+        # fp32-compute parameters (tables / convs / embeddings) are flagged on the tensors themselves
+        for p in (self.spatial_embed.weight, self.spatial_embed.bias):
+            p._o2_lowp = False
+        self.initialize_weights()
+        self._idx_cache = {}
+
+    # ------------------------------------------------------------------ init (res_slimvit.py:125-145)
+    def initialize_weights(self):
+        pe = get_2d_sincos_pos_embed(self.embed_dim, self.img_size[0] // self.patch_size,
+                                     self.img_size[1] // self.patch_size)
+        with torch.no_grad():
+            self.pos_embed.copy_(torch.from_numpy(pe).float().unsqueeze(0))
+
+    def data_config(self, res, img_size, in_channels, out_channels):
+        """Rebinds the run-time data attributes only; no weights change (res_slimvit.py:148-165)."""
+        self.spatial_resolution = res
+        self.img_size = tuple(img_size)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_patches = img_size[0] * img_size[1] // self.patch_size ** 2
+
+    # ------------------------------------------------------------------ helpers
+    def get_var_ids(self, variables: Sequence[str]):
+        return [self.var_map[v] for v in variables]
+
+    def find_var_index(self, in_variables, out_variables):
+        idx = [in_variables.index(v) for v in out_variables]
+        for c in _CONSTS:
+            idx.append(in_variables.index(c))          # ValueError if a constant is missing, as in the reference
+        return idx
+
+    def _chan_idx(self, in_variables, out_variables, device):
+        key = (tuple(in_variables), tuple(out_variables), str(device))
+        t = self._idx_cache.get(key)
+        if t is None:
+            t = torch.tensor(self.find_var_index(list(in_variables), list(out_variables)), dtype=torch.int32,
+                             device=device)
+            self._idx_cache[key] = t
+        return t
+
+    def unpatchify(self, x, scaling=1, out_channels=1):
+        return _ops.UnpatchifyFn.apply(x, out_channels, self.img_size[0], self.img_size[1], self.patch_size, scaling)
+
+    def _tables(self, ids):
+        """Score / value tables of the folded variable aggregation (fp32, autograd through the HIP sgemm)."""
+        D, H = self.embed_dim, self.num_heads
+        dh = D // H
+        wq, wkv = self.var_agg.q.weight, self.var_agg.kv.weight
+        qv = _ops.sgemm(self.var_query.view(1, D), wq, tb=True)                  # [1, D] = var_query Wq^T
+        qblk = torch.block_diag(*qv.view(H, 1, dh).unbind(0))                    # [H, D], head-block structure
+        u = _ops.sgemm(qblk, wkv[:D]) * (dh ** -0.5)                             # [H, D] = scale * q_h^T Wk_h
+        rows = []
+        for v in ids:
+            te = self.token_embeds[v].proj
+            rows.append(torch.cat([te.weight.view(D, 4).t(), (te.bias + self.var_embed[0, v]).view(1, D)], 0))
+        cmat = torch.stack(rows).view(len(ids) * 5, D)                           # [(v,c), D]
+        stab = _ops.sgemm(u, cmat, tb=True).view(H, len(ids), 5)
+        gtab = _ops.sgemm(cmat, wkv[D:], tb=True).view(len(ids), 5, D)
+        return stab, gtab
+
+    def _posres(self):
+        pe = interpolate_pos_embed_on_the_fly(self.pos_embed, self.patch_size, self.img_size)[0]        # [L, D]
+        res = float(self.spatial_resolution)
+        return pe + (self.spatial_embed.weight[:, 0] * res + self.spatial_embed.bias).view(1, -1)
+
+    # ------------------------------------------------------------------ forward (res_slimvit.py:245-338)
+    def forward_encoder(self, x, variables):
+        ids = self.get_var_ids(tuple(variables))
+        stab, gtab = self._tables(ids)
+        p = self.pos_drop_p if self.training else 0.0
+        t = _ops.EmbedFn.apply(x, stab, gtab, self._posres(), self.var_agg.proj.weight, self.var_agg.proj.bias,
+                               self.num_heads, p)
+        for blk in self.blocks:
+            t = blk(t)
+        return t
+
+    def forward(self, x, in_variables, out_variables):
+        if x.dim() == 5:
+            x = x.flatten(1, 2)
+        if not x.is_cuda:
+            raise RuntimeError("Res_Slim_ViT (HIP build) needs its input on a gfx950 device; there is no CPU path")
+        x = x.float().contiguous()
+        B, V, h, w = x.shape
+        if (h, w) != tuple(self.img_size):
+            raise ValueError("input grid %s differs from data_config'd img_size %s" % ((h, w), self.img_size))
+        cidx = self._chan_idx(in_variables, out_variables, x.device)
+        c0, c3 = self.path2[0], self.path2[3]
+        r = _ops.Conv3x3Fn.apply(x, c0.weight, c0.bias, cidx, 1, self.superres_mag, None)
+        r = _ops.Conv3x3Fn.apply(r, c3.weight, c3.bias, None, 0, 1, None)
+        t = self.forward_encoder(x, in_variables)
+        prm = [self.norm.weight, self.norm.bias]
+        for m in self.head:
+            if isinstance(m, HipLinear):
+                prm += [m.weight, m.bias]
+        t = _ops.ChainFn.apply(t, {"ln": True}, *prm)
+        img = self.unpatchify(t, scaling=self.superres_mag, out_channels=self.out_channels)
+        co = self.conv_out
+        return _ops.Conv3x3Fn.apply(img, co.weight, co.bias, None, 0, 1, r)

@@ -1,0 +1,139 @@
+"""Fused AdamW + loss scaler for the HIP path.
+
+HipAdamW has torch.optim.AdamW's math (utils/loaders.py:398-399 of the reference selects torch AdamW) and the
+torch.optim.Optimizer surface (param_groups / state_dict / zero_grad) so LR schedulers drive it unchanged.
+With a HipDataParallel-managed model one fused kernel per flat range updates fp32 master, both moments and the
+bf16 compute copy, and folds in the gradient averaging (1/world) and loss-scale division.
+HipGradScaler mirrors ShardedGradScaler(init_scale=8192, growth_interval=100) + the script's min-scale floor
+(examples/intermediate_downscaling.py:493-497,732-742)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+F32 = torch.float32
+
+
+class HipAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, engine=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.engine = engine
+        self._step = 0
+        self.found_inf = None
+        self.grad_scale = 1.0
+        if engine is not None:
+            self.m = torch.zeros_like(engine.flat32)
+            self.v = torch.zeros_like(engine.flat32)
+            self.found_inf = torch.zeros(1, dtype=F32, device=engine.flat32.device)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._step += 1
+        g = self.param_groups[0]
+        lr, (b1, b2), eps, wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
+        if self.engine is not None:
+            e = self.engine
+            e.finish_grad_sync()
+            gs = self.grad_scale / e.world
+            fi = self.found_inf if self.check_inf else None
+            for o32, o16, n in e.lowp_ranges:
+                _hip.adamw(e.flat32[o32:], self.m[o32:], self.v[o32:], e.g16[o16:], e.flat16[o16:], n, lr, b1, b2, eps,
+                           wd, self._step, gs, fi)
+            for o32, og, n in e.hi_ranges:
+                _hip.adamw(e.flat32[o32:], self.m[o32:], self.v[o32:], e.g32[og:], None, n, lr, b1, b2, eps, wd,
+                           self._step, gs, fi)
+            return None
+        # un-managed parameters (unit tests / tiny models): one launch per tensor
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["m"] = torch.zeros_like(p, dtype=F32)
+                    st["v"] = torch.zeros_like(p, dtype=F32)
+                gr = p.grad.contiguous()
+                p16 = getattr(p, "_o2c", None)
+                _hip.adamw(p.data, st["m"], st["v"], gr, p16, p.numel(), group["lr"], group["betas"][0],
+                           group["betas"][1], group["eps"], group["weight_decay"], self._step, self.grad_scale, None)
+        return None
+
+    check_inf = False
+
+    def zero_grad(self, set_to_none: bool = True):
+        if self.engine is not None:
+            self.engine.zero_grad()
+        else:
+            super().zero_grad(set_to_none)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["orbit2"] = {"step": self._step}
+        if self.engine is not None:
+            sd["orbit2"]["m"] = self.m
+            sd["orbit2"]["v"] = self.v
+        return sd
+
+    def load_state_dict(self, sd):
+        extra = sd.pop("orbit2", None)
+        super().load_state_dict(sd)
+        if extra:
+            self._step = extra["step"]
+            if self.engine is not None and "m" in extra:
+                self.m.copy_(extra["m"])
+                self.v.copy_(extra["v"])
+
+
+class HipGradScaler:
+    """Dynamic loss scaling: scale(loss) -> backward -> step(optimizer) -> update()."""
+
+    def __init__(self, init_scale=8192.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=100,
+                 min_scale=128.0, process_group=None):
+        self._scale = float(init_scale)
+        self.growth_factor, self.backoff_factor = growth_factor, backoff_factor
+        self.growth_interval, self.min_scale = growth_interval, min_scale
+        self._good = 0
+        self.pg = process_group
+        self._found = None
+
+    def get_scale(self):
+        return self._scale
+
+    def scale(self, loss):
+        return loss * self._scale
+
+    def step(self, optimizer: HipAdamW):
+        eng = optimizer.engine
+        assert eng is not None, "HipGradScaler needs a HipDataParallel-managed optimizer"
+        eng.finish_grad_sync()
+        fi = optimizer.found_inf
+        fi.zero_()
+        for _, o16, n in eng.lowp_ranges:
+            _hip.check_finite(eng.g16[o16:], n, fi)
+        for _, og, n in eng.hi_ranges:
+            _hip.check_finite(eng.g32[og:], n, fi)
+        if eng.world > 1:
+            dist.all_reduce(fi, op=dist.ReduceOp.MAX, group=eng.pg)
+        optimizer.grad_scale = 1.0 / self._scale
+        optimizer.check_inf = True
+        optimizer.step()            # the kernel skips the update on device when found_inf != 0
+        optimizer.check_inf = False
+        optimizer.grad_scale = 1.0
+        self._found = fi
+
+    def update(self):
+        bad = bool(self._found.item() != 0.0) if self._found is not None else False
+        if bad:
+            self._scale = max(self._scale * self.backoff_factor, self.min_scale)
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self._scale *= self.growth_factor
+                self._good = 0
+        return bad

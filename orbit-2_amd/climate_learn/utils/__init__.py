@@ -1,0 +1,12 @@
+from .fused_attn import FusedAttn
+from .loaders import (
+    load_model_module,
+    load_forecasting_module,
+    load_downscaling_module,
+    load_climatebench_module,
+    load_architecture,
+    load_optimizer,
+    load_lr_scheduler,
+    load_loss,
+    load_transform,
+)

@@ -330,6 +330,15 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const void* __restric
   if (__any(bad) && (threadIdx.x & 63) == 0) *found = 1.f;
 }
 
+// per-sample DropPath scales (timm DropPath semantics: Bernoulli(keep)/keep per sample), 32-bit threshold
+__global__ void droppath_scales_kernel(float* __restrict__ out, int B, float p, uint64_t seed) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t h = o2_hash64(seed ^ 0xD1B54A32D192ED03ull, (uint64_t)b);
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  out[b] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
+}
+
 inline int grid_for(int64_t work_items, int per_block) {
   int64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -474,6 +483,13 @@ extern "C" int orbit2_check_finite(const void* g, int g_fp32, int64_t n, float* 
   dim3 grid(grid_for(n, 256 * 8)), block(256);
   if (g_fp32) hipLaunchKernelGGL(check_finite_kernel<true>, grid, block, 0, (hipStream_t)stream, g, n, found_inf);
   else hipLaunchKernelGGL(check_finite_kernel<false>, grid, block, 0, (hipStream_t)stream, g, n, found_inf);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_droppath_scales(float* out, int B, float p, uint64_t seed, void* stream) {
+  if (!out || B <= 0 || p < 0.f || p >= 1.f) return O2_ERR_ARG;
+  hipLaunchKernelGGL(droppath_scales_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, out, B, p, seed);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

@@ -230,6 +230,15 @@ def main():
         "v7c3": dict(in_vars=CONST + ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"],
                      out_vars=["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"],
                      grid=(16, 32), run_grid=(16, 32), D=64, depth=2, heads=2, dd=1),
+        # shapes the HIP kernels support (head dim 64, L = 128 tokens): the GPU whole-model parity fixture
+        "v5c1_hd64": dict(in_vars=CONST + ["total_precipitation_24hr"], out_vars=["total_precipitation_24hr"],
+                          grid=(16, 32), run_grid=(16, 32), D=128, depth=2, heads=2, dd=1),
+        "v7c3_hd64": dict(in_vars=["2m_temperature_max", "lattitude", "total_precipitation_24hr", "orography",
+                                   "landcover", "land_sea_mask", "2m_temperature_min"],
+                          out_vars=["2m_temperature_min", "total_precipitation_24hr", "2m_temperature_max"],
+                          default_vars=CONST + ["2m_temperature", "total_precipitation_24hr", "2m_temperature_min",
+                                                "2m_temperature_max"],
+                          grid=(16, 32), run_grid=(16, 32), D=128, depth=1, heads=2, dd=2),
         # data_config'd to a bigger grid than the init grid -> bicubic pos-embed branch; default_vars
         # is a superset of in_vars and in another order -> exercises the var-id gather
         "v6c2_regrid": dict(in_vars=["2m_temperature", "lattitude", "orography", "landcover", "land_sea_mask",

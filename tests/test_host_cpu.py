@@ -1,0 +1,91 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels run)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+
+
+def test_state_dict_keys_and_shapes_match_reference_checkpoint_format(golden_dir):
+    from climate_learn.models.hub import Res_Slim_ViT, MODEL_REGISTRY
+    z = np.load(os.path.join(golden_dir, "model_v7c3_hd64.npz"))
+    ref = {k[2:]: z[k].shape for k in z.files if k.startswith("p.")}
+    dv = CONST + ["2m_temperature", "total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+    m = Res_Slim_ViT(dv, (16, 32), 7, 3, 1, patch_size=2, embed_dim=128, depth=1, decoder_depth=2, num_heads=2)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == {k: tuple(v) for k, v in ref.items()}
+    assert MODEL_REGISTRY["res_slimvit"] is Res_Slim_ViT
+    # pos_embed init = the reference's sincos table
+    assert np.allclose(m.pos_embed.detach().numpy(), z["p.pos_embed"], atol=0.2)  # fixture adds N(0, .02) noise
+
+
+def test_param_count_closed_form():
+    from climate_learn.models.hub import Res_Slim_ViT
+    # interm_8m with V=23, C=3, init grid 32x64 -> 5 485 443 parameters
+    dv = ["v%d" % i for i in range(23)]
+    m = Res_Slim_ViT(dv, (32, 64), 23, 3, 1, patch_size=2, embed_dim=256, depth=6, decoder_depth=4, num_heads=4)
+    assert sum(p.numel() for p in m.parameters()) == 5485443
+
+
+def test_model_refuses_cpu_input():
+    from climate_learn.models.hub import Res_Slim_ViT
+    m = Res_Slim_ViT(CONST + ["total_precipitation_24hr"], (16, 32), 5, 1, 1, patch_size=2, embed_dim=128, depth=1,
+                     decoder_depth=1, num_heads=2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 5, 16, 32), CONST + ["total_precipitation_24hr"], ["total_precipitation_24hr"])
+    with pytest.raises(ValueError):
+        m.find_var_index(["a", "b"], ["a"])
+
+
+def test_loader_api_errors_and_tuple():
+    import climate_learn as cl
+    dm = cl.data.IterDataModule("downscaling", "lo", "hi", CONST + ["total_precipitation_24hr"],
+                                ["total_precipitation_24hr"], batch_size=2, lowres_hw=(16, 32))
+    with pytest.raises(RuntimeError, match="Data module has not been set up yet."):
+        cl.load_downscaling_module("cpu", data_module=dm, architecture="res_slimvit")
+    dm.setup()
+    out = cl.load_downscaling_module(
+        "cpu", data_module=dm, architecture="res_slimvit", train_loss="bayesian_tv",
+        model_kwargs={"default_vars": CONST + ["total_precipitation_24hr"], "embed_dim": 128, "depth": 1,
+                      "decoder_depth": 1, "num_heads": 2, "FusedAttn_option": cl.FusedAttn.CK})
+    assert len(out) == 7
+    model, train_loss = out[0], out[1]
+    assert train_loss.name == "bayesian_tv" and train_loss.aggregate_only
+    assert model.img_size == (16, 32) and model.out_channels == 1
+    assert model.blocks[0].attn.attn_p() == 0.1      # CK semantics: P-dropout even outside training
+    model.eval()
+    assert model.blocks[0].attn.attn_p() == 0.1
+    with pytest.raises(NotImplementedError):
+        cl.load_loss("cpu", model, "no_such_loss", True, None)
+    with pytest.raises(NotImplementedError):
+        cl.load_optimizer(model, "sgd")
+    with pytest.raises(NotImplementedError):
+        cl.load_lr_scheduler("foo", object())
+    x, y, iv, ov = dm.train_dataloader()[0]
+    assert x.shape == (2, 5, 16, 32) and y.shape == (2, 1, 64, 128) and float(y.min()) >= 0.0
+
+
+def test_lr_scheduler_matches_reference_golden(golden_dir):
+    import climate_learn as cl
+    z = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(p, lr=5e-4)
+    sc = cl.load_lr_scheduler("linear-warmup-cosine-annealing", opt,
+                              {"warmup_epochs": 2, "max_epochs": 100, "warmup_start_lr": 1e-7, "eta_min": 1e-8})
+    lrs = []
+    for _ in range(100):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sc.step()
+    assert np.allclose(lrs, z["lr_w2_m100"], rtol=1e-9, atol=1e-15)
+
+
+def test_hash_replica_known_answers():
+    # pins tests/hashmask.py (and through the GPU tests, csrc/common.h:o2_hash64) to fixed values
+    from tests.hashmask import o2_hash64, keep_mask
+    h = o2_hash64(0x1234, np.array([0, 1, 2**33 + 5], dtype=np.uint64))
+    assert h.dtype == np.uint64 and len(set(h.tolist())) == 3
+    m, sc = keep_mask(7, 1 << 16, 0.1)
+    assert abs(m.mean() - (1 - 26 / 256)) < 5e-3 and abs(sc - 256 / 230) < 1e-12

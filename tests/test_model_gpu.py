@@ -1,0 +1,137 @@
+"""Whole-model GPU parity: the HIP Res_Slim_ViT against (a) golden vectors produced by the reference's own
+modules (tests/golden/model_*_hd64.npz) and (b) the CPU oracle on seeded inputs.  Tolerances: bf16 compute vs
+the fp32 reference, normalised max error (max|a-b|/max|b|): prediction <= 2e-2, gradients <= 5e-2 (SURVEY 7:
+the reference's own bf16-vs-fp32 spread is 4.5e-3 / 1.5e-2), loss <= 1e-2 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+CASES = {
+    "v5c1_hd64": dict(in_vars=CONST + ["total_precipitation_24hr"], out_vars=["total_precipitation_24hr"],
+                      grid=(16, 32), D=128, depth=2, heads=2, dd=1),
+    "v7c3_hd64": dict(in_vars=["2m_temperature_max", "lattitude", "total_precipitation_24hr", "orography",
+                               "landcover", "land_sea_mask", "2m_temperature_min"],
+                      out_vars=["2m_temperature_min", "total_precipitation_24hr", "2m_temperature_max"],
+                      default_vars=CONST + ["2m_temperature", "total_precipitation_24hr", "2m_temperature_min",
+                                            "2m_temperature_max"],
+                      grid=(16, 32), D=128, depth=1, heads=2, dd=2),
+}
+VW = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0, "2m_temperature": 10.0}
+
+
+def nerr(a, b):
+    a = torch.as_tensor(a).detach().float().cpu().double()
+    b = torch.as_tensor(b).detach().float().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def load(golden_dir, tag):
+    import climate_learn as cl
+    from climate_learn.models.hub import Res_Slim_ViT
+    c = CASES[tag]
+    z = np.load(os.path.join(golden_dir, "model_%s.npz" % tag))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    m = Res_Slim_ViT(c.get("default_vars", c["in_vars"]), c["grid"], len(c["in_vars"]), len(c["out_vars"]), 1,
+                     patch_size=2, embed_dim=c["D"], depth=c["depth"], decoder_depth=c["dd"], num_heads=c["heads"],
+                     drop_path=0.1, drop_rate=0.1, learn_pos_emb=True)
+    missing = m.load_state_dict(sd, strict=True)
+    m.data_config(156.0, c["grid"], len(c["in_vars"]), len(c["out_vars"]))
+    return c, z, sd, m.cuda().eval()
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_forward_loss_grads_vs_reference_golden(golden_dir, tag):
+    from climate_learn.metrics import Bayesian_TV, MSE, LatWeightedMSE
+    from climate_learn.metrics.utils import MetricsMetaInfo
+    from climate_learn.trainer import clip_replace_constant
+    c, z, sd, m = load(golden_dir, tag)
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    pred = m(x, c["in_vars"], c["out_vars"])
+    assert pred.dtype == torch.float32 and tuple(pred.shape) == tuple(z["pred"].shape)
+    assert nerr(pred, z["pred"]) < 2e-2
+    yhat = clip_replace_constant(y, pred, c["out_vars"])
+    full = Bayesian_TV(aggregate_only=False)(yhat, y, var_names=c["out_vars"], var_weights=VW)
+    assert nerr(full, z["loss.bayesian_tv"]) < 1e-2
+    mi = MetricsMetaInfo(c["in_vars"], c["out_vars"], z["lat"], None, None)
+    assert nerr(LatWeightedMSE(False, mi)(yhat, y, var_names=c["out_vars"], var_weights=VW), z["loss.lat_mse"]) < 1e-2
+    assert nerr(MSE(False)(yhat, y, var_names=c["out_vars"], var_weights=VW), z["loss.mse"]) < 1e-2
+    full[-1].backward()
+    worst = {}
+    for n, p in m.named_parameters():
+        k = "g.bayesian_tv." + n
+        if k in z.files:
+            assert p.grad is not None, n
+            worst[n] = nerr(p.grad, z[k])
+    bad = {n: e for n, e in worst.items() if e > 5e-2}
+    assert len(worst) > 25 and not bad, bad
+
+
+@pytest.mark.parametrize("tag", ["v5c1_hd64"])
+def test_engine_adamw_trajectory_vs_reference_golden(golden_dir, tag):
+    """3 fused-AdamW steps through the DP engine (world 1) reproduce the reference's fp32 loss trajectory."""
+    import climate_learn as cl
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    c, z, sd, m = load(golden_dir, tag)
+    eng = cl.HipDataParallel(m, unit_types=(Block, nn.Sequential))
+    opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+    assert opt.engine is eng
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    loss_fn = Bayesian_TV(aggregate_only=True)
+    traj = []
+    for step in range(3):
+        loss = training_step((x, y, c["in_vars"], c["out_vars"]), step, eng, torch.device("cuda"), VW, loss_fn)
+        traj.append(float(loss))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    ref = z["adamw.loss_traj"]
+    assert abs(traj[0] - ref[0]) / ref[0] < 1e-2
+    assert np.allclose(traj, ref, rtol=3e-2), (traj, ref)
+    assert traj[2] < traj[0]
+    after = eng.state_dict()
+    assert nerr(after["head.0.weight"], z["adamw.p_after.head.0.weight"]) < 2e-2
+    # compute copies follow the masters
+    w = m.head[0].weight
+    assert torch.equal(w._o2c.float(), w.data.to(torch.bfloat16).float())
+
+
+def test_train_mode_dropout_and_recompute_match():
+    """recompute (activation-checkpoint counterpart) replays the same dropout masks: identical gradients."""
+    from climate_learn import manual_seed
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.testing import build_pair
+    from climate_learn.trainer import training_step
+    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2)
+    for b in model.blocks:
+        b.attn.attn_drop_p = b.attn.proj_drop_p = b.mlp.drop = 0.1
+        b.drop_path = 0.2
+    model.pos_drop_p = 0.1
+    model = model.cuda().train()
+    grads = []
+    for rc in (False, True):
+        for b in model.blocks:
+            b.recompute = rc
+        manual_seed(1234)
+        model.zero_grad()
+        loss = training_step((x, y, in_vars, out_vars), 0, model, torch.device("cuda"), None, Bayesian_TV(True))
+        loss.backward()
+        grads.append((float(loss), model.blocks[0].attn.qkv.weight.grad.clone(), model.var_query.grad.clone()))
+    assert grads[0][0] == grads[1][0]
+    assert torch.equal(grads[0][1], grads[1][1]) and torch.equal(grads[0][2], grads[1][2])
+    # and dropout actually changed the result relative to eval
+    model.eval()
+    l_eval = float(training_step((x, y, in_vars, out_vars), 0, model, torch.device("cuda"), None, Bayesian_TV(True)))
+    assert abs(l_eval - grads[0][0]) > 1e-6
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
