@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: climate-grid samples/s (fwd + loss + bwd + DP all-reduce + AdamW) of the HIP
+Res_Slim_ViT training step.  Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
+launched as one rank per GPU by torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+Workload at N=1 (and per GPU at N>1, weak scaling): BASELINE.json configs[2] -- interm_1b (D3072/depth 8/
+24 heads/decoder 4), ERA5 1.40625deg -> 0.25deg synthetic grids: x [B,23,128,256] -> pred [B,3,512,1024],
+target [B,3,721,1440] consumed through its top-left 512x1024 crop, bf16 compute / fp32 master, train mode with
+the YAML's dropout 0.1 / drop-path 0.1, loss bayesian_tv, dynamic loss scaling, fused AdamW.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "orbit-2_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+ERA5_VARS = CONST + [
+    "2m_temperature", "2m_temperature_max", "2m_temperature_min", "temperature_200", "temperature_500",
+    "temperature_850", "10m_u_component_of_wind", "u_component_of_wind_200", "u_component_of_wind_500",
+    "u_component_of_wind_850", "10m_v_component_of_wind", "v_component_of_wind_200", "v_component_of_wind_500",
+    "v_component_of_wind_850", "specific_humidity_200", "specific_humidity_500", "specific_humidity_850",
+    "total_precipitation_24hr", "volumetric_soil_water_layer_1"]
+OUT_VARS = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+VAR_WEIGHTS = {"2m_temperature": 10, "10m_u_component_of_wind": 1, "10m_v_component_of_wind": 1,
+               "total_precipitation_24hr": 1, "2m_temperature_min": 10, "2m_temperature_max": 10}
+MODELS = {  # configs/interm_*.yaml of the reference
+    "interm_8m": dict(embed_dim=256, depth=6, num_heads=4),
+    "interm_117m": dict(embed_dim=1024, depth=8, num_heads=16),
+    "interm_1b": dict(embed_dim=3072, depth=8, num_heads=24),
+}
+PEAK_BF16 = 2.5e15   # dense MFMA peak, MI355X_MICROARCH.md
+METRIC = "climate-grid samples/sec/node (fwd+bwd), interm_1b ERA5 1.4°→0.25°, 1/2/4/8 GPUs"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="interm_1b")
+    ap.add_argument("--grid", default="128x256")
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--recompute", action="store_true", help="replay each Block in backward (activation ckpt)")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, V, C):
+    """Oracle (CPU restatement of the reference math, kind 'port') timed on the host: same model, a 32x64 tile of
+    the grid (L=512), batch 1, fp32, fwd+loss+bwd+AdamW; scaled to full-grid samples/s by the FLOP ratio."""
+    from oracle import orbit2_oracle as O
+    m = MODELS[model_name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    grid = (32, 64)
+    cfg = O.Config(ERA5_VARS, grid, C, m["embed_dim"], m["depth"], 4, m["num_heads"], spatial_resolution=156.0)
+    g = torch.Generator().manual_seed(0)
+    shapes = O.init_state_dict(O.Config(ERA5_VARS, grid, C, 64, 1, 1, 4), V)     # key set only
+    del shapes
+    # fast init (values do not affect timing): N(0, 0.02)
+    tiny = O.Config(ERA5_VARS, grid, C, 8 * m["num_heads"], m["depth"], 4, m["num_heads"])
+    proto = O.init_state_dict(tiny, V)
+    D, d0 = m["embed_dim"], 8 * m["num_heads"]
+    sd = {}
+    for k, v in proto.items():
+        shape = tuple((D if s == d0 else 2 * D if s == 2 * d0 else 3 * D if s == 3 * d0 else 4 * D if s == 4 * d0 else s)
+                      for s in v.shape)
+        sd[k] = (torch.randn(shape, generator=g) * 0.02).requires_grad_()
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
+    x = torch.randn(1, V, *grid, generator=g)
+    y = torch.randn(1, C, 4 * grid[0], 4 * grid[1], generator=g).abs()
+    names = list(sd)
+
+    def step(i):
+        loss = O.training_loss(sd, cfg, x, y, ERA5_VARS, OUT_VARS, "bayesian_tv", VAR_WEIGHTS)
+        grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+        with torch.no_grad():
+            for k, gr in zip(names, grads):
+                if gr is not None:
+                    O.adamw_step(sd[k], gr, mom[k][0], mom[k][1], i, 5e-4, 0.9, 0.99, 1e-8, 1e-5)
+
+    step(1)
+    t0 = time.perf_counter()
+    n = 2
+    for i in range(n):
+        step(2 + i)
+    dt = (time.perf_counter() - t0) / n
+    f_tile = O.forward_flops(512, V, D, m["depth"], 4, C, 32, 64, m["num_heads"])
+    f_full = O.forward_flops(8192, V, D, m["depth"], 4, C, 128, 256, m["num_heads"])
+    return {"value": (1.0 / dt) * f_tile / f_full, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle (plain PyTorch fp32) fwd+loss+bwd+AdamW of %s on one 32x64 tile (L=512), batch 1, "
+                      "%d timed steps of %.2f s; scaled to 128x256 samples/s by the dense-FLOP ratio %.4f"
+                      % (model_name, n, dt, f_tile / f_full)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import climate_learn as cl
+    from climate_learn import _hip
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub import Res_Slim_ViT
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    from oracle.orbit2_oracle import forward_flops   # FLOP model only (no compute)
+
+    m = MODELS[a.model]
+    h, w = (int(v) for v in a.grid.split("x"))
+    V, C, B = len(ERA5_VARS), len(OUT_VARS), a.batch
+    L = h * w // 4
+    drop = 0.0 if a.no_dropout else 0.1
+    torch.manual_seed(0)
+    cl.manual_seed(0, rank)
+    with torch.device(dev):
+        model = Res_Slim_ViT(ERA5_VARS, (h, w), V, C, 1, superres_mag=4, cnn_ratio=4, patch_size=2, drop_path=drop,
+                             drop_rate=drop, learn_pos_emb=True, embed_dim=m["embed_dim"], depth=m["depth"],
+                             decoder_depth=4, num_heads=m["num_heads"], mlp_ratio=4, FusedAttn_option=cl.FusedAttn.HIP)
+    model.data_config(156.0, (h, w), V, C)
+    for blk in model.blocks:
+        blk.recompute = a.recompute
+    nparams = sum(p.numel() for p in model.parameters())
+    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential))
+    opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0)
+    loss_fn = Bayesian_TV(aggregate_only=True)
+    eng.train()
+
+    # synthetic ERA5-shaped batch, resident in HBM before the timed region (SURVEY 8d input recipe)
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, V, h, w, generator=g)
+    gc = torch.Generator().manual_seed(7)
+    for i in range(4):
+        x[:, i] = torch.randn(h, w, generator=gc)
+    hy, wy = (721, 1440) if (h, w) == (128, 256) else (4 * h, 4 * w)
+    y = torch.randn(B, C, hy, wy, generator=g)
+    y[:, 0] = torch.log1p(torch.relu(y[:, 0]))
+    batch = (x.to(dev), y.to(dev), ERA5_VARS, OUT_VARS)
+
+    def step(i):
+        loss = training_step(batch, i, eng, dev, VAR_WEIGHTS, loss_fn)
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    _hip.timer = _hip.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        last = step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _hip.timer.summary()
+    _hip.timer = None
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(last)
+
+    if rank == 0:
+        sps = world * B * a.steps / dt
+        f_dense = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"])
+        f_exec = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"], folded_varagg=True)
+        gm = prof.get("gemm_bf16", {"work": 0.0, "ms": 1.0, "launches": 0})
+        ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["launches"] else 0.0
+        out = {
+            "metric": METRIC, "value": sps, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s Res_Slim_ViT bf16 (fp32 master), ERA5 1.40625deg->0.25deg synthetic: x[%d,%d,%d,%d] "
+                                   "-> pred[%d,%d,%d,%d], target %dx%d cropped; fwd+bayesian_tv loss+bwd+grad all-reduce+"
+                                   "loss-scaled fused AdamW; dropout %.1f, drop-path %.1f"
+                                   % (a.model, B, V, h, w, B, C, 4 * h, 4 * w, hy, wy, drop, drop),
+                       "per_gpu_batch": B, "global_batch": B * world, "tokens_per_sample": L, "params": nparams,
+                       "parallelism": "dp%d" % world, "activation_recompute": bool(a.recompute)},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": ach / (PEAK_BF16 / 1e12), "traffic": None,
+                         "kernel": "gemm128_kernel (orbit2_gemm_bf16)", "launches": gm["launches"],
+                         "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
+            "step_model": {
+                "model_flops_per_sample_dense": 3 * f_dense, "executed_flops_per_sample_folded_varagg": 3 * f_exec,
+                "mfma_frac_of_peak_dense_formulation": 3 * f_dense * sps / world / PEAK_BF16,
+                "mfma_frac_of_peak_executed": 3 * f_exec * sps / world / PEAK_BF16,
+                "attn_fwd_tflops": (prof["attn_fwd"]["work"] / prof["attn_fwd"]["ms"] / 1e9) if "attn_fwd" in prof else None,
+                "attn_bwd_tflops": (prof["attn_bwd"]["work"] / prof["attn_bwd"]["ms"] / 1e9) if "attn_bwd" in prof else None,
+                "gemm_ms_per_step": gm["ms"] / a.steps,
+                "attn_ms_per_step": (prof.get("attn_fwd", {"ms": 0})["ms"] + prof.get("attn_bwd", {"ms": 0})["ms"]) / a.steps,
+                "final_loss": loss_val, "loss_scale": scaler.get_scale()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            del eng, opt, model, batch
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(a.model, V, C)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,30 @@ def _dev(t: torch.Tensor, dtype, name: str):
 BF, F32 = torch.bfloat16, torch.float32
 
 
+class KernelTimer:
+    """Optional live timing of individual launches with HIP events recorded on the launch stream
+    (bench.py uses it for the roofline of the dominant kernel).  Off unless `_hip.timer` is set."""
+
+    def __init__(self):
+        self.records = {}      # name -> [ (work, ev0, ev1) ]
+
+    def span(self, name, work):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(name, []).append((work, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for _, a, b in recs]
+            out[name] = {"launches": len(recs), "work": float(sum(w for w, _, _ in recs)), "ms": float(sum(ms))}
+        return out
+
+
+timer: Optional[KernelTimer] = None
+
+
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None, dgelu_pre=None,
          drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0, res_first=False,
@@ -106,6 +130,12 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act
     a.ldr, a.res_mod, a.res_first = ldr, res_mod, int(res_first)
     a.out_fp32 = int(out.dtype == F32)
     a.beta = float(beta)
+    if timer is not None:
+        e0, e1 = timer.span("gemm_bf16", 2.0 * M * N * K)
+        e0.record()
+        _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
+        e1.record()
+        return out
     _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
     return out
 
@@ -148,8 +178,13 @@ def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0):
     _dev(qkv, BF, "qkv")
     out = torch.empty(B, L, H * d, dtype=BF, device=qkv.device)
     lse = torch.empty(B, H, L, dtype=F32, device=qkv.device)
+    if timer is not None:
+        e0, e1 = timer.span("attn_fwd", 4.0 * B * H * L * L * d)
+        e0.record()
     _chk(lib().orbit2_attn_fwd(_p(qkv), _p(out), _p(lse), B, L, H, d, C.c_float(drop_p), C.c_uint64(seed), _stream()),
          "orbit2_attn_fwd")
+    if timer is not None:
+        e1.record()
     return out, lse
 
 
@@ -157,8 +192,13 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, d, drop_p=0.0, seed=0):
     _dev(qkv, BF, "qkv"); _dev(out, BF, "out"); _dev(dout, BF, "dout"); _dev(lse, F32, "lse")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, L, dtype=F32, device=qkv.device)
+    if timer is not None:
+        e0, e1 = timer.span("attn_bwd", 8.0 * B * H * L * L * d)     # algorithmic: 2x forward (recompute not credited)
+        e0.record()
     _chk(lib().orbit2_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, L, H, d,
                                C.c_float(drop_p), C.c_uint64(seed), _stream()), "orbit2_attn_bwd")
+    if timer is not None:
+        e1.record()
     return dqkv
 
 
