@@ -80,6 +80,20 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
   return r;
 }
 
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast_c(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xf, 0xf, true);
+}
+// value of lane (4*(lane/4) + j); j is a compile-time constant after unrolling
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {
+  switch (j) {
+    case 0: return quad_bcast_c<0>(v);
+    case 1: return quad_bcast_c<1>(v);
+    case 2: return quad_bcast_c<2>(v);
+    default: return quad_bcast_c<3>(v);
+  }
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // dropout on a 32x32 tile whose lane-local axis (registers) runs along KEYS: registers 4t..4t+3 are keys
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // backward, dQ: same geometry as the forward (query on the lane)
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                              const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __res
 // backward, dK/dV: key on the lane; the workgroup owns 128 keys (32 per wave) and sweeps all queries
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
@@ -416,6 +430,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
         s = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s);
         dp = MFMA32(row_frag<D>(sdo, qb * 32 + (lane & 31), ds, hq), vf[ds], dp);
       }
+      // dropout: one hash covers 4 consecutive keys = the 4 lanes of a quad; each lane hashes 4 of the 16
+      // query rows (rows r with (r&3) == lane&3) and the quad shares them by DPP broadcast.
+      uint32_t hmine[4] = {0u, 0u, 0u, 0u};
+      if (thr) {
+        const int l3 = lane & 3;
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+          const uint64_t qg = (uint64_t)(t * 64 + qb * 32 + l3 + 8 * tq + 4 * hq);
+          hmine[tq] = o2_hash64(seed, ((bh * L + qg) * (uint64_t)L + (uint64_t)krow) >> 2);
+        }
+      }
+      const int kbyte = 8 * (krow & 3);
       f32x16 pd;  // P after dropout (for dV)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -424,10 +450,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
         float dpr = dp[r];
         float pdr = p;
         if (thr) {
-          const uint64_t qg = (uint64_t)(t * 64 + ql);
-          const uint64_t idx = ((bh * L + qg) * (uint64_t)L + (uint64_t)krow) >> 2;
-          const uint32_t hh = o2_hash64(seed, idx);
-          const bool keep = ((hh >> (8 * (krow & 3))) & 0xffu) >= thr;
+          const uint32_t hh = quad_bcast(hmine[r >> 2], r & 3);
+          const bool keep = ((hh >> kbyte) & 0xffu) >= thr;
           dpr = keep ? dpr * dscale : 0.f;
           pdr = keep ? p * dscale : 0.f;
         }

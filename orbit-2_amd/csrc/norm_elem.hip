@@ -144,21 +144,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// out[which][col] = beta*out + sum_p part[p][which][col]
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D, void* dgamma, void* dbeta,
-                                     int fp32, float beta) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * D) return;
-  const int which = e / D, col = e - which * D;
+// out[which][col] = beta*out + sum_p part[p][which][col]; 32 columns x 8 partial-groups per block
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D,
+                                                            void* dgamma, void* dbeta, int fp32, float beta) {
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + tx;          // flat (which, col) index in [0, 2D)
   float s = 0.f;
-  for (int p = 0; p < nblk; ++p) s += part[((size_t)p * 2 + which) * D + col];
-  void* dst = which ? dbeta : dgamma;
-  if (fp32) {
-    float* o = (float*)dst + col;
-    *o = s + (beta != 0.f ? beta * *o : 0.f);
-  } else {
-    bf16_t* o = (bf16_t*)dst + col;
-    *o = f2bf(s + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+  if (e < 2 * D) {
+    const int which = e / D, col = e - which * D;
+    for (int p = ty; p < nblk; p += 8) s += part[((size_t)p * 2 + which) * D + col];
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && e < 2 * D) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][tx];
+    const int which = e / D, col = e - which * D;
+    void* dst = which ? dbeta : dgamma;
+    if (fp32) {
+      float* o = (float*)dst + col;
+      *o = t + (beta != 0.f ? beta * *o : 0.f);
+    } else {
+      bf16_t* o = (bf16_t*)dst + col;
+      *o = f2bf(t + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+    }
   }
 }
 
@@ -194,37 +205,70 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restri
   }
 }
 
-// ---- column sums: stage 1 partials [P][N], stage 2 reduce ---------------------------------------
-constexpr int CS_ROWS = 64;
+// ---- column sums: stage 1 partials [P][N] (16-byte loads, 8 row-lanes per block), stage 2 reduce ----------
+constexpr int CS_ROWS = 128;
 template <bool FP32>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict__ xv, int M, int N, int ldx,
                                                           float* __restrict__ part) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  __shared__ float red[8][32][9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + tx) * 8;
   const int r0 = blockIdx.y * CS_ROWS;
   const int r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
-  float s = 0.f;
-  if (FP32) {
-    const float* x = (const float*)xv;
-    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + col];
-  } else {
-    const bf16_t* x = (const bf16_t*)xv;
-    for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ldx + col]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    if (FP32) {
+      const float* x = (const float*)xv;
+      for (int r = r0 + ty; r < r1; r += 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + c0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + c0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+      }
+    } else {
+      const bf16_t* x = (const bf16_t*)xv;
+      for (int r = r0 + ty; r < r1; r += 8) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + c0), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      }
+    }
   }
-  part[(size_t)blockIdx.y * N + col] = s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx][j] = acc[j];
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][tx][j];
+      part[(size_t)blockIdx.y * N + c0 + j] = t;
+    }
+  }
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, int P, int N, void* out, int out_fp32,
-                                     float beta) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int P, int N, void* out,
+                                                            int out_fp32, float beta) {
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(size_t)p * N + col];
-  if (out_fp32) {
-    float* o = (float*)out + col;
-    *o = s + (beta != 0.f ? beta * *o : 0.f);
-  } else {
-    bf16_t* o = (bf16_t*)out + col;
-    *o = f2bf(s + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+  if (col < N)
+    for (int p = ty; p < P; p += 8) s += part[(size_t)p * N + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][tx];
+    if (out_fp32) {
+      float* o = (float*)out + col;
+      *o = t + (beta != 0.f ? beta * *o : 0.f);
+    } else {
+      bf16_t* o = (bf16_t*)out + col;
+      *o = f2bf(t + (beta != 0.f ? beta * bf2f(*o) : 0.f));
+    }
   }
 }
 
@@ -392,7 +436,7 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
   LN_DISPATCH(nc, CALL);
 #undef CALL
   O2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, ws, nparts, D, dgamma, dbeta,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, nparts, D, dgamma, dbeta,
                      grads_fp32, beta_acc);
   O2_CHECK_LAUNCH();
   return O2_OK;
@@ -418,11 +462,12 @@ extern "C" int orbit2_colsum(const void* x, int x_fp32, int M, int N, int ldx, v
   const int P = (M + CS_ROWS - 1) / CS_ROWS;
   if (ws_floats < P * N) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if ((N & 7) || (ldx & 7)) return O2_ERR_ARG;
   dim3 g1((N + 255) / 256, P);
   if (x_fp32) hipLaunchKernelGGL(colsum_part_kernel<true>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
   else hipLaunchKernelGGL(colsum_part_kernel<false>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
   O2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, P, N, out, out_fp32, beta);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, ws, P, N, out, out_fp32, beta);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
