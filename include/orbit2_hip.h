@@ -48,6 +48,7 @@ typedef struct {
   int ldr, res_mod, res_first;
   int out_fp32;            /* 0: C is bf16, 1: C is fp32 */
   float beta;              /* C = beta*C + result (gradient accumulation) */
+  int tile_hint;           /* 0 = auto, 128 or 256 = force that kernel (tests / tuning) */
 } orbit2_gemm_args;
 int orbit2_gemm_bf16(const orbit2_gemm_args* args, void* stream);
 

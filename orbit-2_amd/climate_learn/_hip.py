@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("ldr", C.c_int), ("res_mod", C.c_int), ("res_first", C.c_int),
         ("out_fp32", C.c_int),
         ("beta", C.c_float),
+        ("tile_hint", C.c_int),
     ]
 
 
@@ -109,7 +110,7 @@ timer: Optional[KernelTimer] = None
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None, dgelu_pre=None,
          drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0, res_first=False,
-         beta=0.0):
+         beta=0.0, tile=0):
     """out[M,N] = epilogue(A x B); see include/orbit2_hip.h:orbit2_gemm_bf16."""
     for t, nm in ((A, "A"), (B, "B")):
         _dev(t, BF, nm)
@@ -130,6 +131,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act
     a.ldr, a.res_mod, a.res_first = ldr, res_mod, int(res_first)
     a.out_fp32 = int(out.dtype == F32)
     a.beta = float(beta)
+    a.tile_hint = int(tile)
     if timer is not None:
         e0, e1 = timer.span("gemm_bf16", 2.0 * M * N * K)
         e0.record()

@@ -67,10 +67,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rbase, int db, i
   const int row1 = row + 8;
   const char* a1 = tile + row1 * Cfg<D>::RB + ((c ^ swz<D>(row1)) << 4) + 8 * (p & 1);
   const bf16x4 lo = lds_tr4(a0), hi = lds_tr4(a1);
-  bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {

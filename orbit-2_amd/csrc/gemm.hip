@@ -57,10 +57,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int r0, int kk, in
     const char* a = tile + krow * 256 + ((((r0 >> 4) ^ sw)) << 5) + 8 * pp;
     const bf16x4 lo = lds_tr4(a);
     const bf16x4 hi = lds_tr4(a + 4 * 256);
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
 
@@ -223,6 +220,163 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const bf16_t* __restric
   }
 }
 
+// ==========================================================================================
+// 256x256x32 tile, 512 threads = 8 waves (2x4), wave tile 128x64 (8x4 fragments), 4-stage LDS ring
+// (4 x 32 KiB).  LDS-DMA runs three stages ahead of the MFMAs behind a COUNTED s_waitcnt vmcnt and a raw
+// s_barrier, so global loads stay in flight across barriers (one barrier per 32 MFMAs per wave).
+//   K-contiguous operand : image [256 rows][32 k] (64-B rows), 16-B chunk c stored at c ^ f(row>>2),
+//                          f = {0,2,3,1}: conflict-free for the 4x16-lane groups of ds_read_b128.
+//   K-strided operand    : image [32 k][256 cols] (512-B rows), 32-B granule (low 3 bits) ^= (k&3)|((k>>3)&1)<<2.
+// ==========================================================================================
+constexpr int BM2 = 256, BN2 = 256, BK2 = 32;
+constexpr int STAGE2 = 2 * 256 * 32 * 2;  // A + B, 32 KiB
+constexpr int NSTAGE2 = 4;
+
+__device__ __forceinline__ int swz_kc32(int row) {
+  const int q = (row >> 2) & 3;
+  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_tile2(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0,
+                                            char* tile, int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = wave * 2 + t;  // instruction id 0..15 (1 KiB each) of this 16 KiB operand tile
+    const bf16_t* src;
+    if (KC) {
+      const int row = i * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ swz_kc32(row);
+      int gr = r0 + row;
+      gr = gr < rmax ? gr : rmax - 1;
+      src = G + (size_t)gr * ld + k0 + chunk * 8;
+    } else {
+      const int krow = i * 2 + (lane >> 5);
+      const int cp = lane & 31;
+      const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int gran = cp >> 1;
+      const int chunk = ((((gran & 8) | ((gran & 7) ^ sw))) << 1) | (cp & 1);
+      int col = r0 + chunk * 8;
+      col = col <= rmax - 8 ? col : rmax - 8;
+      src = G + (size_t)(k0 + krow) * ld + col;
+    }
+    glds16(src, tile + i * 1024);
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag2(const char* tile, int r0, int lane) {
+  if (KC) {
+    const int row = r0 + (lane & 15);
+    const int chunk = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((chunk ^ swz_kc32(row)) << 4));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int krow = 8 * g + q;
+    const int sw = q | ((g & 1) << 2);
+    const int gran = r0 >> 4;
+    const char* a = tile + krow * 512 + (((gran & 8) | ((gran & 7) ^ sw)) << 5) + 8 * pp;
+    const bf16x4 lo = lds_tr4(a);
+    const bf16x4 hi = lds_tr4(a + 4 * 512);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         int M, int N, int K, int lda, int ldb, int tiles_m,
+                                                         int tiles_n, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE2 * STAGE2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  constexpr int GROUP = 4;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsz;
+  const int tn = (id % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK2;
+  // Ring protocol.  Invariant at the top of iteration kt (after the barrier that ended kt-1): stages <= kt+1
+  // have landed for every wave, this wave's fragments of stage kt are in registers (cur set), stages kt+2 and
+  // kt+3 are in flight.  Iteration kt: (1) refill the slot of stage kt with stage kt+4, (2) read the fragments
+  // of stage kt+1 into the other register set while (3) the 32 MFMAs of stage kt run, (4) counted vmcnt so that
+  // stage kt+2 has landed (kt+3, kt+4 stay in flight), lgkmcnt(0) so nobody's fragment reads are pending when
+  // a slot is refilled, raw s_barrier.
+  // (stages past the end re-load the last K-slab into a dead slot: keeps the loop branch-free and the vmcnt
+  //  arithmetic constant -- every step issues exactly 4 LDS-DMA instructions per wave)
+  auto issue = [&](int st) {
+    const int kst = st < nk ? st : nk - 1;
+    char* d = smem + (st & 3) * STAGE2;
+    stage_tile2<A_KC>(A, lda, m0, M, kst * BK2, d, wave, lane);
+    stage_tile2<B_KC>(B, ldb, n0, N, kst * BK2, d + STAGE2 / 2, wave, lane);
+  };
+  issue(0); issue(1); issue(2); issue(3);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stages 0 and 1 landed (this wave's part)
+  __builtin_amdgcn_s_barrier();
+  bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+  {
+    const char* sa = smem;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb0[j] = read_frag2<B_KC>(sa + STAGE2 / 2, wn * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = read_frag2<A_KC>(sa, wm * 128 + i * 16, lane);
+  }
+#define O2_RING_STEP(KT, FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                                   \
+  {                                                                                                        \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): cur fragments complete, slot of stage KT is free */   \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    issue((KT) + 4);                                                                                       \
+    {                                                                                                      \
+      const int nx_ = (KT) + 1 < nk ? (KT) + 1 : nk - 1;                                                   \
+      const char* sa_ = smem + (nx_ & 3) * STAGE2;                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+          FB_NXT[j] = read_frag2<B_KC>(sa_ + STAGE2 / 2, wn * 64 + j * 16, lane);                          \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
+          FA_NXT[i] = read_frag2<A_KC>(sa_, wm * 128 + i * 16, lane);                                      \
+    }                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_CUR[j], FA_CUR[i], acc[i][j], 0, 0, 0);     \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                     \
+  }
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    O2_RING_STEP(kt, fa0, fb0, fa1, fb1)
+    O2_RING_STEP(kt + 1, fa1, fb1, fa0, fb0)
+  }
+  if (kt < nk) O2_RING_STEP(kt, fa0, fb0, fa1, fb1)
+#undef O2_RING_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      epilogue4(epi, m, n, acc[i][j]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // small fp32 GEMM (table algebra; sizes ~ [115 x D] x [D x D]): 64x64 tile, 16x16 threads, 4x4 micro-tile
 // ------------------------------------------------------------------------------------------
@@ -304,11 +458,43 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   e.thr = (unsigned)(a->drop_p * 256.0f + 0.5f);
   e.dscale = 256.0f / (256.0f - (float)e.thr);
   e.beta = a->beta;
-  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t* A = (const bf16_t*)a->A;
   const bf16_t* B = (const bf16_t*)a->B;
+  // tile choice: the 256^2 ring kernel (1 workgroup/CU) needs enough tiles to fill the chip; the 128^2 kernel
+  // (2 workgroups/CU) takes small or ragged problems.  tile_hint forces one (tests / tuning).
+  const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+  int tile = a->tile_hint;
+  if (tile != 128 && tile != 256) {
+    // measured on MI355X (tools/gemm_bench.py, interm_1b shapes, random data): the ring kernel wins for the
+    // K-contiguous form with long K or very wide N; the 128^2 kernel (2 workgroups/CU hide prologue/epilogue)
+    // wins elsewhere, in particular for both K-strided forms.
+    const long rounds = (t256 + 255) / 256;
+    const double util = (double)t256 / (double)(rounds * 256);
+    const bool nt = a->a_kc && a->b_kc;
+    tile = (nt && a->K % BK2 == 0 && a->M >= 256 && a->N >= 256 && t256 >= 200 && util >= 0.70 &&
+            (a->K >= 6144 || a->N >= 9216)) ? 256 : 128;
+  }
+  if (tile == 256) {
+    const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
+    dim3 grid(tiles_m * tiles_n), block(512);
+    if (a->a_kc && a->b_kc)
+      hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    else if (a->a_kc && !a->b_kc)
+      hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    else if (!a->a_kc && a->b_kc)
+      hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    else
+      hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
+  }
+  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n), block(256);
   if (a->a_kc && a->b_kc)
     hipLaunchKernelGGL((gemm128_kernel<true, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
                        tiles_m, tiles_n, e);

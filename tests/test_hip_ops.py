@@ -42,9 +42,10 @@ def test_selftest_layout_maps(hip):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (136, 200, 128), (1024, 1024, 512)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (136, 200, 128), (1024, 1024, 512), (520, 776, 192)])
 @pytest.mark.parametrize("form", ["nt", "nn", "tn", "tt"])
-def test_gemm_forms(hip, M, N, K, form):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_forms(hip, M, N, K, form, tile):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = rt(torch.randn(M, K, generator=g))
     B = rt(torch.randn(N, K, generator=g))
@@ -54,11 +55,11 @@ def test_gemm_forms(hip, M, N, K, form):
     Ad = bf(A if a_kc else A.t().contiguous()).cuda()
     Bd = bf(B if b_kc else B.t().contiguous()).cuda()
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    hip.gemm(Ad, Bd, out, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc)
+    hip.gemm(Ad, Bd, out, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, tile=tile)
     torch.cuda.synchronize()
     assert nerr(out, ref) < 2e-5   # fp32 out: only accumulation-order differences
     outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    hip.gemm(Ad, Bd, outb, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc)
+    hip.gemm(Ad, Bd, outb, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, tile=tile)
     assert nerr(outb, ref) < 6e-3  # one bf16 rounding of the result (2^-8 relative)
 
 
