@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference driver examples/intermediate_downscaling.py for the MI355X HIP path.
+
+Same CLI (`python intermediate_downscaling.py <config.yaml>`), same YAML schema (trainer / parallelism / tiling /
+model / data, reference configs/interm_*.yaml), same environment contract (SLURM_NTASKS / SLURM_PROCID /
+SLURM_LOCALID / HOSTNAME, with a torchrun-style RANK / WORLD_SIZE / LOCAL_RANK fallback), same per-step prints
+and the same checkpoint dictionary keys and paths (reference :775-795).  Differences by decision:
+  * the data-parallel engine is climate_learn.HipDataParallel (the FSDP NO_SHARD + bf16 MixedPrecision
+    equivalent); fsdp / tensor_par / seq_par degrees other than 1 are rejected (out of the hot-path scope);
+  * the bf16 branch uses HipGradScaler(init_scale=8192, growth_interval=100, min_scale=128) -- the behaviour
+    the reference intends at :493-497 (where it raises NameError);
+  * data comes from the synthetic IterDataModule (the npz data plane is SURVEY 8f-1).
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "orbit-2_amd"))
+
+import climate_learn as cl  # noqa: E402
+from climate_learn.data.processing.era5_constants import CONSTANTS  # noqa: E402,F401
+from climate_learn.dist.profile import *  # noqa: E402,F401,F403
+from climate_learn.models.hub.components.pos_embed import interpolate_pos_embed  # noqa: E402
+from climate_learn.models.hub.components.vit_blocks import Block  # noqa: E402
+from climate_learn.trainer import training_step  # noqa: E402
+from climate_learn.utils.fused_attn import FusedAttn  # noqa: E402
+
+
+def seed_everything(seed, rank=0):
+    torch.manual_seed(seed)
+    cl.manual_seed(seed, rank)
+
+
+def init_par_groups(world_rank, data_par_size, tensor_par_size, seq_par_size, fsdp_size, simple_ddp_size, world_size):
+    """Reference :161-262.  Only the pure data-parallel layout is accepted."""
+    assert seq_par_size == 1, "Sequence parallelism not implemented"
+    assert tensor_par_size == 1, "tensor parallelism is outside the MI355X hot-path build"
+    assert fsdp_size == 1, "sharded FSDP is SURVEY 8f-4 (next); use simple_ddp"
+    assert data_par_size * seq_par_size * tensor_par_size == world_size, \
+        "DATA_PAR_SIZE * SEQ_PAR_SIZE * TENSOR_PAR_SIZE must equal to world_size"
+    group = dist.new_group(list(range(world_size))) if world_size > 1 else None
+    return group
+
+
+def load_checkpoint(model, path, rank):
+    if rank == 0:
+        print("model resume from checkpoint", path, flush=True)
+    ck = torch.load(path, map_location="cpu")
+    sd = ck["model_state_dict"]
+    interpolate_pos_embed(model, sd, new_size=model.img_size)
+    model.load_state_dict(sd)
+    return ck
+
+
+def main():
+    cfg_path = sys.argv[1]
+    conf = yaml.load(open(cfg_path), Loader=yaml.FullLoader)
+    world_size = int(os.environ.get("SLURM_NTASKS", os.environ.get("WORLD_SIZE", "1")))
+    world_rank = int(os.environ.get("SLURM_PROCID", os.environ.get("RANK", "0")))
+    local_rank = int(os.environ.get("SLURM_LOCALID", os.environ.get("LOCAL_RANK", "0")))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", rank=world_rank, world_size=world_size, device_id=device)
+
+    tr, par, mc, dc = conf["trainer"], conf["parallelism"], conf["model"], conf["data"]
+    max_epochs, batch_size = tr["max_epochs"], tr["batch_size"]
+    data_type, train_loss_str = tr.get("data_type", "bfloat16"), tr["train_loss"]
+    if data_type not in ("bfloat16", "float32"):
+        raise RuntimeError("Data type not supported")
+    tiling = conf.get("tiling", {}) or {}
+    div, overlap = (tiling.get("div", 1), tiling.get("overlap", 0)) if tiling.get("do_tiling", False) else (1, 0)
+    fsdp_size, ddp_size = par.get("fsdp", 1), par.get("simple_ddp", 1)
+    tp, sp = par.get("tensor_par", 1), par.get("seq_par", 1)
+    dp_group = init_par_groups(world_rank, fsdp_size * ddp_size, tp, sp, fsdp_size, ddp_size, world_size)
+
+    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0) if data_type == "bfloat16" else None
+    model = eng = optimizer = scheduler = None
+    epoch_start = 0
+    seed_everything(0, world_rank)
+    for data_key in dc["low_res_dir"]:
+        in_vars, out_vars = dc["dict_in_variables"][data_key], dc["dict_out_variables"][data_key]
+        syn = (dc.get("synthetic") or {}).get(data_key, {})
+        dm = cl.data.IterDataModule(
+            "downscaling", dc["low_res_dir"][data_key], dc["high_res_dir"][data_key], in_vars, out_vars=out_vars,
+            data_par_size=world_size, data_par_group=dp_group, subsample=1, batch_size=batch_size,
+            buffer_size=tr.get("buffer_size", 0), num_workers=tr.get("num_workers", 0), div=div, overlap=overlap,
+            lowres_hw=tuple(syn.get("lowres_hw", (32, 64))), highres_hw=tuple(syn["highres_hw"]) if "highres_hw" in syn else None,
+            steps_per_epoch=syn.get("steps_per_epoch", 4))
+        dm.setup()
+        if model is None:
+            with torch.device(device):
+                out = cl.load_downscaling_module(
+                    device, data_module=dm, architecture=mc["preset"], train_loss=train_loss_str,
+                    model_kwargs={"default_vars": dc["default_vars"], "superres_mag": mc["superres_mag"],
+                                  "cnn_ratio": mc["cnn_ratio"], "patch_size": mc["patch_size"],
+                                  "embed_dim": mc["embed_dim"], "depth": mc["depth"],
+                                  "decoder_depth": mc["decoder_depth"], "num_heads": mc["num_heads"],
+                                  "mlp_ratio": mc["mlp_ratio"], "drop_path": mc["drop_path"],
+                                  "drop_rate": mc["drop_rate"], "tensor_par_size": 1, "tensor_par_group": None,
+                                  "FusedAttn_option": FusedAttn.CK if data_type == "bfloat16" else FusedAttn.DEFAULT})
+            model, train_loss = out[0], out[1]
+            ck = None
+            if tr.get("checkpoint") and os.path.exists(str(tr["checkpoint"])):
+                ck = load_checkpoint(model, tr["checkpoint"], world_rank)
+            print("enter NO SHARD only,", flush=True)
+            eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
+                                     sync_module_states=True)
+            for blk in model.blocks:
+                blk.recompute = bool(tr.get("activation_checkpointing", False))
+            optimizer = cl.load_optimizer(eng, "adamw", {"lr": float(mc["lr"]), "weight_decay": float(mc["weight_decay"]),
+                                                         "betas": (mc["beta_1"], mc["beta_2"])})
+            scheduler = cl.load_lr_scheduler("linear-warmup-cosine-annealing", optimizer,
+                                             {"warmup_epochs": mc["warmup_epochs"], "max_epochs": max_epochs,
+                                              "warmup_start_lr": float(mc["warmup_start_lr"]),
+                                              "eta_min": float(mc["eta_min"])})
+            if ck is not None:
+                optimizer.load_state_dict(ck["optimizer_state_dict"])
+                scheduler.load_state_dict(ck["scheduler_state_dict"])
+                epoch_start = ck["epoch"] + 1
+        in_shape, _ = dm.get_data_dims()
+        eng.data_config(dc["spatial_resolution"][data_key], tuple(in_shape[2:]), len(in_vars), len(out_vars))
+        var_weights = dc.get("var_weights", {})
+        for epoch in range(epoch_start, max_epochs):
+            eng.train()
+            epoch_loss = torch.zeros((), dtype=torch.float32, device=device)
+            if world_rank == 0:
+                print("epoch ", epoch, flush=True)
+            for batch_idx, batch in enumerate(dm.train_dataloader()):
+                if world_rank == 0:
+                    torch.cuda.synchronize(device)
+                    tic1 = time.perf_counter()
+                loss = training_step(batch, batch_idx, eng, device, var_weights, train_loss)
+                epoch_loss += loss.detach()
+                if world_rank == 0:
+                    print("epoch: ", epoch, "batch_idx", batch_idx, "world_rank", world_rank, " loss ", float(loss), flush=True)
+                optimizer.zero_grad()
+                if scaler is None:
+                    loss.backward()
+                    optimizer.step()
+                else:
+                    scaler.scale(loss).backward()
+                    scaler.step(optimizer)
+                    scaler.update()
+                if world_rank == 0:
+                    torch.cuda.synchronize(device)
+                    print("rank", world_rank, "batch_idx", batch_idx, "get_lr ", scheduler.get_last_lr(),
+                          "after optimizer step torch.cuda.memory_reserved: %fGB" % (torch.cuda.memory_reserved(device) / 2 ** 30),
+                          flush=True)
+                    print(f"my rank {world_rank}. tic4-tic1 in {(time.perf_counter() - tic1):0.4f} seconds\n", flush=True)
+            scheduler.step()
+            if world_rank == 0:
+                print("epoch: ", epoch, " epoch_loss ", float(epoch_loss), flush=True)
+                os.makedirs("checkpoints/climate", exist_ok=True)
+                torch.save({"epoch": epoch, "model_state_dict": eng.state_dict(),
+                            "optimizer_state_dict": optimizer.state_dict(),
+                            "scheduler_state_dict": scheduler.state_dict()},
+                           "checkpoints/climate/interm_epoch_" + str(epoch) + ".ckpt")
+            if world_size > 1:
+                dist.barrier()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""World-size-2 `gloo` tests of the data-parallel engine (bucket layout, readiness counting, all-reduce of the
+bf16 and fp32 gradient buckets, parameter broadcast).  CPU only: no kernels run -- the backward kernels'
+behaviour (write into p._o2g, call grad_ready) is simulated."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    from climate_learn.models.hub import Res_Slim_ViT
+    consts = ["land_sea_mask", "orography", "lattitude", "landcover"]
+    return Res_Slim_ViT(consts + ["total_precipitation_24hr"], (16, 32), 5, 1, 1, patch_size=2, embed_dim=128, depth=2,
+                        decoder_depth=1, num_heads=2)
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import climate_learn as cl
+        from climate_learn.models.hub.components.vit_blocks import Block
+        torch.manual_seed(100 + rank)               # different init per rank -> broadcast must equalise
+        model = _build()
+        eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential), overlap=False)
+        # 1. sync_module_states: every rank holds rank 0's parameters
+        ref = [torch.zeros_like(eng.flat32) for _ in range(world)]
+        dist.all_gather(ref, eng.flat32)
+        assert all(torch.equal(r, ref[0]) for r in ref)
+        # 2. layout: units = 2 Blocks + path2 + head + root; state_dict stays fp32 with the reference's keys
+        names = [b.name for b in eng.buckets]
+        assert names == ["blocks.0", "blocks.1", "path2", "head", "root"], names
+        sd = eng.state_dict()
+        assert all(v.dtype == torch.float32 for v in sd.values()) and "blocks.1.mlp.fc2.weight" in sd
+        w = model.blocks[0].attn.qkv.weight
+        assert w._o2c.dtype == torch.bfloat16 and w._o2g.shape == w.shape and w.data.data_ptr() >= eng.flat32.data_ptr()
+        assert torch.equal(w._o2c.float(), w.data.to(torch.bfloat16).float())
+        assert not hasattr(model.var_agg.kv.weight, "_o2g")      # fp32-compute parameter: grads via .grad view
+        # 3. simulated backward: every rank writes rank-dependent gradients, buckets reduce as they fill
+        eng.zero_grad()
+        order = []
+        orig = eng._launch
+        eng._launch = lambda bk: (order.append(bk.name), orig(bk))[1]
+        for bk in reversed(eng.buckets):
+            for p in bk.params:
+                if hasattr(p, "_o2g"):
+                    assert p._o2_fresh
+                    p._o2g.fill_(float(rank + 1))
+                    p._o2_fresh = False
+                    eng.grad_ready(p)
+                else:
+                    p.grad.add_(float(rank + 1) * 0.5)
+                    eng._hi_hook(p)
+        assert order == ["root", "head", "path2", "blocks.1", "blocks.0"], order
+        eng.finish_grad_sync()
+        tot = sum(range(1, world + 1))
+        assert torch.all(w._o2g.float() == tot)
+        assert torch.all(model.conv_out.weight.grad == 0.5 * tot)
+        assert torch.all(model.var_agg.kv.weight.grad == 0.5 * tot)
+        # 4. zero_grad resets readiness and the fp32 bucket
+        eng.zero_grad()
+        assert float(eng.g32.abs().sum()) == 0.0 and all(b.pending > 0 for b in eng.buckets) and w._o2_fresh
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_engine_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_engine_single_process_layout():
+    import climate_learn as cl
+    from climate_learn.models.hub.components.vit_blocks import Block
+    model = _build()
+    n = sum(p.numel() for p in model.parameters())
+    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential), overlap=False)
+    assert eng.world == 1
+    lo = sum(x[2] for x in eng.lowp_ranges)
+    hi = sum(x[2] for x in eng.hi_ranges)
+    assert lo + hi == eng.flat32.numel() and eng.flat32.numel() >= n
+    # every parameter is a view into the master buffer, 256-byte aligned
+    base = eng.flat32.data_ptr()
+    for p in model.parameters():
+        off = p.data.data_ptr() - base
+        assert 0 <= off < eng.flat32.numel() * 4 and off % 256 == 0
