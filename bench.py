@@ -66,17 +66,8 @@ def cpu_baseline(model_name, V, C):
     grid = (32, 64)
     cfg = O.Config(ERA5_VARS, grid, C, m["embed_dim"], m["depth"], 4, m["num_heads"], spatial_resolution=156.0)
     g = torch.Generator().manual_seed(0)
-    shapes = O.init_state_dict(O.Config(ERA5_VARS, grid, C, 64, 1, 1, 4), V)     # key set only
-    del shapes
-    # fast init (values do not affect timing): N(0, 0.02)
-    tiny = O.Config(ERA5_VARS, grid, C, 8 * m["num_heads"], m["depth"], 4, m["num_heads"])
-    proto = O.init_state_dict(tiny, V)
-    D, d0 = m["embed_dim"], 8 * m["num_heads"]
-    sd = {}
-    for k, v in proto.items():
-        shape = tuple((D if s == d0 else 2 * D if s == 2 * d0 else 3 * D if s == 3 * d0 else 4 * D if s == 4 * d0 else s)
-                      for s in v.shape)
-        sd[k] = (torch.randn(shape, generator=g) * 0.02).requires_grad_()
+    sd = {k: v.requires_grad_() for k, v in O.init_state_dict(cfg, V, seed=0, fast=True).items()}
+    D = m["embed_dim"]
     mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
     x = torch.randn(1, V, *grid, generator=g)
     y = torch.randn(1, C, 4 * grid[0], 4 * grid[1], generator=g).abs()
@@ -193,6 +184,13 @@ def main():
         f_dense = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"])
         f_exec = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"], folded_varagg=True)
         gm = prof.get("gemm_bf16", {"work": 0.0, "ms": 1.0, "launches": 0})
+        traffic = None     # HBM bytes per GEMM launch from the committed PMC passes of the same configuration
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj["_config"] == {"model": a.model, "batch": B, "grid": a.grid}:
+                traffic = tj["gemm"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["launches"] else 0.0
         out = {
             "metric": METRIC, "value": sps, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
@@ -205,7 +203,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_sample": L, "params": nparams,
                        "parallelism": "dp%d" % world, "activation_recompute": bool(a.recompute)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": ach / (PEAK_BF16 / 1e12), "traffic": None,
+                         "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": gm.get("bytes", None),
                          "kernel": "gemm128_kernel (orbit2_gemm_bf16)", "launches": gm["launches"],
                          "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
             "step_model": {

@@ -152,7 +152,7 @@ class Config:
         self.spatial_resolution = spatial_resolution
 
 
-def init_state_dict(cfg: Config, n_in: int, seed: int = 0, init_grid=None) -> Dict[str, torch.Tensor]:
+def init_state_dict(cfg: Config, n_in: int, seed: int = 0, init_grid=None, fast: bool = False) -> Dict[str, torch.Tensor]:
     """Random-init weights with the reference's shapes and init laws (res_slimvit.py:125-145:
     Linear trunc_normal(0.02)/bias 0, LayerNorm 1/0, conv default, var_embed/var_query zeros,
     pos_embed sincos).  RNG stream differs from the reference's (parity unpinned for init values)."""
@@ -163,8 +163,11 @@ def init_state_dict(cfg: Config, n_in: int, seed: int = 0, init_grid=None) -> Di
     sd: Dict[str, torch.Tensor] = {}
 
     def lin(name, o, i, bias=True):
-        w = torch.empty(o, i)
-        torch.nn.init.trunc_normal_(w, std=0.02, generator=g)
+        if fast:        # timing-only init (bench cpu_baseline): plain N(0, 0.02), no truncation
+            w = torch.randn(o, i, generator=g) * 0.02
+        else:
+            w = torch.empty(o, i)
+            torch.nn.init.trunc_normal_(w, std=0.02, generator=g)
         sd[name + ".weight"] = w
         if bias:
             sd[name + ".bias"] = torch.zeros(o)

@@ -90,17 +90,18 @@ class KernelTimer:
     def __init__(self):
         self.records = {}      # name -> [ (work, ev0, ev1) ]
 
-    def span(self, name, work):
+    def span(self, name, work, nbytes=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.setdefault(name, []).append((work, e0, e1))
+        self.records.setdefault(name, []).append((work, e0, e1, nbytes))
         return e0, e1
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
-            ms = [a.elapsed_time(b) for _, a, b in recs]
-            out[name] = {"launches": len(recs), "work": float(sum(w for w, _, _ in recs)), "ms": float(sum(ms))}
+            ms = [r[1].elapsed_time(r[2]) for r in recs]
+            out[name] = {"launches": len(recs), "work": float(sum(r[0] for r in recs)), "ms": float(sum(ms)),
+                         "bytes": float(sum(r[3] for r in recs)) / max(1, len(recs))}
         return out
 
 
@@ -133,7 +134,8 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act
     a.beta = float(beta)
     a.tile_hint = int(tile)
     if timer is not None:
-        e0, e1 = timer.span("gemm_bf16", 2.0 * M * N * K)
+        e0, e1 = timer.span("gemm_bf16", 2.0 * M * N * K,
+                            2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0))
         e0.record()
         _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
         e1.record()
