@@ -109,7 +109,7 @@ __device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
                                                           unsigned thr, float dscale, uint64_t seed) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int i = 0; i < C::NDB; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    if (thr) {
+    if (DROP) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) drop_keys_in_regs(s[kb], seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
     }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =============================================================================================
 // backward, dQ: same geometry as the forward (query on the lane)
 // =============================================================================================
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                              const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse,
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s);
         dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], dp);
       }
-      if (thr) drop_keys_in_regs(dp, seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
+      if (DROP) drop_keys_in_regs(dp, seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse2);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // =============================================================================================
 // backward, dK/dV: key on the lane; the workgroup owns 128 keys (32 per wave) and sweeps all queries
 // =============================================================================================
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(c
       // dropout: one hash covers 4 consecutive keys = the 4 lanes of a quad; each lane hashes 4 of the 16
       // query rows (rows r with (r&3) == lane&3) and the quad shares them by DPP broadcast.
       uint32_t hmine[4] = {0u, 0u, 0u, 0u};
-      if (thr) {
+      if (DROP) {
         const int l3 = lane & 3;
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(c
         float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - s_lse[ql]);
         float dpr = dp[r];
         float pdr = p;
-        if (thr) {
+        if (DROP) {
           const uint32_t hh = quad_bcast(hmine[r >> 2], r & 3);
           const bool keep = ((hh >> kbyte) & 0xffu) >= thr;
           dpr = keep ? dpr * dscale : 0.f;
@@ -507,12 +507,12 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   const float dscale = 256.0f / (256.0f - (float)thr);
   dim3 grid(L / 128, H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (d == 128)
-    hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
-                       thr, dscale, seed);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
-                       thr, dscale, seed);
+#define O2_FWD(DV, DR)                                                                                              \
+  hipLaunchKernelGGL((attn_fwd_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H,   \
+                     sc_log2, thr, dscale, seed)
+  if (d == 128) { if (thr) O2_FWD(128, true); else O2_FWD(128, false); }
+  else { if (thr) O2_FWD(64, true); else O2_FWD(64, false); }
+#undef O2_FWD
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
@@ -531,17 +531,16 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
                      (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
   O2_CHECK_LAUNCH();
   dim3 grid(L / 128, H, B), block(256);
-  if (d == 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                       delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                       delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
-                       (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                       delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);
-  }
+#define O2_BWD(DV, DR)                                                                                               \
+  do {                                                                                                               \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout,    \
+                       lse, delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);                                  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout,   \
+                       lse, delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);                                  \
+  } while (0)
+  if (d == 128) { if (thr) O2_BWD(128, true); else O2_BWD(128, false); }
+  else { if (thr) O2_BWD(64, true); else O2_BWD(64, false); }
+#undef O2_BWD
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
