@@ -61,9 +61,14 @@ def cpu_baseline(model_name, V, C):
     the grid (L=512), batch 1, fp32, fwd+loss+bwd+AdamW; scaled to full-grid samples/s by the FLOP ratio."""
     from oracle import orbit2_oracle as O
     m = MODELS[model_name]
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # the GPU box grants a 16-core CPU share per GPU
     torch.set_num_threads(cores)
-    grid = (32, 64)
+    grid = (16, 32)
+    print("[bench] cpu_baseline: oracle on %d threads, tile %dx%d ..." % (cores, grid[0], grid[1]), file=sys.stderr, flush=True)
     cfg = O.Config(ERA5_VARS, grid, C, m["embed_dim"], m["depth"], 4, m["num_heads"], spatial_resolution=156.0)
     g = torch.Generator().manual_seed(0)
     sd = {k: v.requires_grad_() for k, v in O.init_state_dict(cfg, V, seed=0, fast=True).items()}
@@ -82,17 +87,19 @@ def cpu_baseline(model_name, V, C):
                     O.adamw_step(sd[k], gr, mom[k][0], mom[k][1], i, 5e-4, 0.9, 0.99, 1e-8, 1e-5)
 
     step(1)
+    print("[bench] cpu_baseline: warm-up step done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     n = 2
     for i in range(n):
         step(2 + i)
+        print("[bench] cpu_baseline: timed step %d done" % (i + 1), file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / n
-    f_tile = O.forward_flops(512, V, D, m["depth"], 4, C, 32, 64, m["num_heads"])
+    f_tile = O.forward_flops(grid[0] * grid[1] // 4, V, D, m["depth"], 4, C, grid[0], grid[1], m["num_heads"])
     f_full = O.forward_flops(8192, V, D, m["depth"], 4, C, 128, 256, m["num_heads"])
     return {"value": (1.0 / dt) * f_tile / f_full, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle (plain PyTorch fp32) fwd+loss+bwd+AdamW of %s on one 32x64 tile (L=512), batch 1, "
-                      "%d timed steps of %.2f s; scaled to 128x256 samples/s by the dense-FLOP ratio %.4f"
-                      % (model_name, n, dt, f_tile / f_full)}
+            "sample": "oracle (plain PyTorch fp32) fwd+loss+bwd+AdamW of %s on one %dx%d tile (L=%d), batch 1, "
+                      "%d timed steps of %.2f s; scaled to 128x256 samples/s by the dense-FLOP ratio %.5f"
+                      % (model_name, grid[0], grid[1], grid[0] * grid[1] // 4, n, dt, f_tile / f_full)}
 
 
 def main():
