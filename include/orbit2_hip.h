@@ -99,6 +99,8 @@ int orbit2_colsum_ws_floats(int M, int N);
 int orbit2_batch_sum(const void* x, void* out, int B, int rows, int N, int out_fp32, float beta, void* stream);
 /* DropPath (timm 0.9.2, vit_blocks.py:61,74): out[b] = 0 with prob p else 1/(1-p), from hash(seed, b) */
 int orbit2_droppath_scales(float* out, int B, float p, uint64_t seed, void* stream);
+/* dst[C][R] = src[R][C] (bf16): transposed compute copy of a weight so that dX = dY.W runs K-contiguous */
+int orbit2_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
 int orbit2_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int orbit2_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* y = a + b (bf16), used for pos_embed + spatial_embed table (res_slimvit.py:273-281) */

@@ -379,3 +379,10 @@ def droppath_scales(B, p, seed, device):
     out = torch.empty(B, dtype=F32, device=device)
     _chk(lib().orbit2_droppath_scales(_p(out), B, C.c_float(p), C.c_uint64(seed), _stream()), "orbit2_droppath_scales")
     return out
+
+
+def transpose_bf16(src, dst):
+    _dev(src, BF, "src"); _dev(dst, BF, "dst")
+    R, Cc = src.shape
+    _chk(lib().orbit2_transpose_bf16(_p(src), _p(dst), R, Cc, _stream()), "orbit2_transpose_bf16")
+    return dst

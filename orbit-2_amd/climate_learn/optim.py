@@ -47,6 +47,7 @@ class HipAdamW(torch.optim.Optimizer):
             for o32, og, n in e.hi_ranges:
                 _hip.adamw(e.flat32[o32:], self.m[o32:], self.v[o32:], e.g32[og:], None, n, lr, b1, b2, eps, wd,
                            self._step, gs, fi)
+            e.refresh_transposed_copies()
             return None
         # un-managed parameters (unit tests / tiny models): one launch per tensor
         for group in self.param_groups:

@@ -312,14 +312,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / BK2;
-  // Ring protocol.  Invariant at the top of iteration kt (after the barrier that ended kt-1): stages <= kt+1
-  // have landed for every wave, this wave's fragments of stage kt are in registers (cur set), stages kt+2 and
-  // kt+3 are in flight.  Iteration kt: (1) refill the slot of stage kt with stage kt+4, (2) read the fragments
-  // of stage kt+1 into the other register set while (3) the 32 MFMAs of stage kt run, (4) counted vmcnt so that
-  // stage kt+2 has landed (kt+3, kt+4 stay in flight), lgkmcnt(0) so nobody's fragment reads are pending when
-  // a slot is refilled, raw s_barrier.
-  // (stages past the end re-load the last K-slab into a dead slot: keeps the loop branch-free and the vmcnt
-  //  arithmetic constant -- every step issues exactly 4 LDS-DMA instructions per wave)
+  // Ring protocol (4 slots of one 32-deep K-slab each), two barriers per K-slab, the two waves of every SIMD
+  // (wave w and w+4) STAGGERED by one barrier so that one of them issues MFMAs while the other one loads:
+  //   L(kt): refill the slot of stage kt with stage kt+4 (LDS-DMA), read the fragments of stage kt+1 into the
+  //          spare register set, lgkmcnt(0)
+  //   M(kt): 32 MFMAs on the fragments of stage kt; counted vmcnt(4): stage kt+3 has landed, kt+4 stays in flight
+  //   A (waves 0-3):  L(0) | M(0) | L(1) | M(1) | ...        B (waves 4-7):  -- | L(0) | M(0) | L(1) | ...
+  // Hazards (| = s_barrier): a slot is refilled in L(kt) only after every wave has read stage kt's fragments
+  // (A: L(kt-1), B: L(kt-1) which ends one barrier before A's L(kt)); fragments of stage kt+1 are read only after
+  // every wave's share of that stage has landed (waited for at the end of M(kt-2), >= one barrier earlier).
+  // Stages past the end re-load the last K-slab into a dead slot: branch-free loop, constant vmcnt arithmetic.
   auto issue = [&](int st) {
     const int kst = st < nk ? st : nk - 1;
     char* d = smem + (st & 3) * STAGE2;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     stage_tile2<B_KC>(B, ldb, n0, N, kst * BK2, d + STAGE2 / 2, wave, lane);
   };
   issue(0); issue(1); issue(2); issue(3);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stages 0 and 1 landed (this wave's part)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
   {
@@ -337,10 +339,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa0[i] = read_frag2<A_KC>(sa, wm * 128 + i * 16, lane);
   }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();            // every wave holds its stage-0 fragments: slot 0 may be refilled
+  if (wave >= 4) __builtin_amdgcn_s_barrier();   // stagger the second wave of every SIMD by one phase
 #define O2_RING_STEP(KT, FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                                   \
   {                                                                                                        \
-    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): cur fragments complete, slot of stage KT is free */   \
-    __builtin_amdgcn_s_barrier();                                                                          \
     issue((KT) + 4);                                                                                       \
     {                                                                                                      \
       const int nx_ = (KT) + 1 < nk ? (KT) + 1 : nk - 1;                                                   \
@@ -350,12 +353,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
       _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
           FA_NXT[i] = read_frag2<A_KC>(sa_, wm * 128 + i * 16, lane);                                      \
     }                                                                                                      \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                   \
+    __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_CUR[j], FA_CUR[i], acc[i][j], 0, 0, 0);     \
     __builtin_amdgcn_s_setprio(0);                                                                         \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                     \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                       \
+    __builtin_amdgcn_s_barrier();                                                                          \
   }
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   }
   if (kt < nk) O2_RING_STEP(kt, fa0, fb0, fa1, fb1)
 #undef O2_RING_STEP
+  if (wave < 4) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
 
 #pragma unroll
@@ -466,14 +473,13 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
   if (tile != 128 && tile != 256) {
-    // measured on MI355X (tools/gemm_bench.py, interm_1b shapes, random data): the ring kernel wins for the
-    // K-contiguous form with long K or very wide N; the 128^2 kernel (2 workgroups/CU hide prologue/epilogue)
-    // wins elsewhere, in particular for both K-strided forms.
+    // measured on MI355X (tools/gemm_bench.py, interm_1b shapes, random data, profiles/r01_gemm_bench_shapes.txt):
+    // the staggered ring kernel wins for the K-contiguous (NT) form whenever it can fill the chip; the 128^2
+    // kernel (2 workgroups/CU) wins for both K-strided forms and for small / ragged problems.
     const long rounds = (t256 + 255) / 256;
     const double util = (double)t256 / (double)(rounds * 256);
     const bool nt = a->a_kc && a->b_kc;
-    tile = (nt && a->K % BK2 == 0 && a->M >= 256 && a->N >= 256 && t256 >= 200 && util >= 0.70 &&
-            (a->K >= 6144 || a->N >= 9216)) ? 256 : 128;
+    tile = (nt && a->K % BK2 == 0 && a->M >= 256 && a->N >= 256 && t256 >= 192 && util >= 0.70) ? 256 : 128;
   }
   if (tile == 256) {
     const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;

@@ -306,6 +306,24 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(const bf16_t* __restric
     y[i] = f2bf(bf2f(a[i]) + bf2f(vec[i % N]));
 }
 
+// ---- bf16 matrix transpose through LDS: dst[C][R] = src[R][C]  (transposed compute copies of the weights so
+//      that the input-gradient GEMM dX = dY . W runs in the K-contiguous form) ---------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(size_t)c * R + r] = tile[tx][i];
+  }
+}
+
 // ---- AdamW ---------------------------------------------------------------------------------
 template <bool GFP32>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -535,6 +553,14 @@ extern "C" int orbit2_check_finite(const void* g, int g_fp32, int64_t n, float* 
 extern "C" int orbit2_droppath_scales(float* out, int B, float p, uint64_t seed, void* stream) {
   if (!out || B <= 0 || p < 0.f || p >= 1.f) return O2_ERR_ARG;
   hipLaunchKernelGGL(droppath_scales_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, out, B, p, seed);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0) return O2_ERR_ARG;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, R, C);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
