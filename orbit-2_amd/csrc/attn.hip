@@ -102,7 +102,7 @@ __device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint
     const uint64_t idx = (rowbase + (uint64_t)(kbase + 8 * t + 4 * h)) >> 2;
     const uint32_t hh = o2_hash64(seed, idx);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) p[4 * t + e] = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] * dscale : 0.f;
+    for (int e = 0; e < 4; ++e) p[4 * t + e] = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : 0.f;
   }
 }
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     cur ^= 1;
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
+  const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
   if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
   bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
 #pragma unroll
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
   const size_t sidx = ((size_t)(b * H + head)) * L + qrow;
   const float lse2 = lse[sidx] * 1.4426950408889634f;
-  const float dlt = delta[sidx];
+  const float dlt = DROP ? delta[sidx] / dscale : delta[sidx];   // dscale folded into the final scale
   const uint64_t rowbase = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)L;
 
   f32x16 dq[C::NDB];
@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int g4 = 0; g4 < 4; ++g4) {
       const int dd = db * 32 + 8 * g4 + 4 * hq;
       u32x2 w;
-      w[0] = pack_bf2(dq[db][4 * g4] * scale, dq[db][4 * g4 + 1] * scale);
-      w[1] = pack_bf2(dq[db][4 * g4 + 2] * scale, dq[db][4 * g4 + 3] * scale);
+      const float fs = DROP ? scale * dscale : scale;
+      w[0] = pack_bf2(dq[db][4 * g4] * fs, dq[db][4 * g4 + 1] * fs);
+      w[1] = pack_bf2(dq[db][4 * g4 + 2] * fs, dq[db][4 * g4 + 3] * fs);
       *reinterpret_cast<u32x2*>(drow + dd) = w;
     }
 }
@@ -353,14 +354,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // =============================================================================================
 // backward, dK/dV: key on the lane; the workgroup owns 128 keys (32 per wave) and sweeps all queries
 // =============================================================================================
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
+// WHICH: 0 = dK and dV in one pass (d = 64: fits 2 waves/SIMD);  1 = dK only;  2 = dV only.
+// At d = 128 the fused form needs 236 VGPR + 160 AGPR (1 wave/SIMD, measured 576 TFLOP/s executed); split in two
+// passes (5 MFMA products instead of 4) each pass fits 2 waves/SIMD.
+template <int D, bool DROP, int WHICH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                               unsigned thr, float dscale, uint64_t seed) {
   using C = Cfg<D>;
+  constexpr bool DO_DK = WHICH != 2, DO_DV = WHICH != 1;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // [2][Q|dO] + [2][lse2|delta]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -377,25 +382,30 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(c
   const float sc_log2 = scale * 1.4426950408889634f;
   float* sstat = reinterpret_cast<float*>(smem + 4 * C::TILE);
 
-  bf16x8 kf[C::NDS], vf[C::NDS];
+  bf16x8 kf[C::NDS], vf[DO_DK ? C::NDS : 1];
 #pragma unroll
   for (int ds = 0; ds < C::NDS; ++ds) {
     kf[ds] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
-    vf[ds] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
+    if (DO_DK) vf[ds] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
   }
-  f32x16 dk[C::NDB], dv[C::NDB];
+  f32x16 dk[DO_DK ? C::NDB : 1], dv[DO_DV ? C::NDB : 1];
 #pragma unroll
   for (int i = 0; i < C::NDB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+      if (DO_DK) dk[i][r] = 0.f;
+      if (DO_DV) dv[i][r] = 0.f;
+    }
 
   const size_t sbase = ((size_t)(b * H + head)) * L;
   const uint64_t bh = (uint64_t)(b * H + head);
+  const uint32_t lq = (uint32_t)(L >> 2);   // L % 128 == 0
   const int nt = L / 64;
   auto stage_stats = [&](int t, int buf) {
     if (tid < 128) {
       const int which = tid >> 6, i = tid & 63;
-      const float v = which ? delta[sbase + t * 64 + i] : lse[sbase + t * 64 + i] * 1.4426950408889634f;
+      const float v = which ? (DROP ? delta[sbase + t * 64 + i] / dscale : delta[sbase + t * 64 + i])
+                            : lse[sbase + t * 64 + i] * 1.4426950408889634f;
       sstat[(buf * 2 + which) * 64 + i] = v;
     }
   };
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 #pragma unroll
       for (int ds = 0; ds < C::NDS; ++ds) {
         s = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s);
-        dp = MFMA32(row_frag<D>(sdo, qb * 32 + (lane & 31), ds, hq), vf[ds], dp);
+        if (DO_DK) dp = MFMA32(row_frag<D>(sdo, qb * 32 + (lane & 31), ds, hq), vf[ds], dp);
       }
       // dropout: one hash covers 4 consecutive keys = the 4 lanes of a quad; each lane hashes 4 of the 16
       // query rows (rows r with (r&3) == lane&3) and the quad shares them by DPP broadcast.
@@ -434,35 +444,46 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(c
         const int l3 = lane & 3;
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {
-          const uint64_t qg = (uint64_t)(t * 64 + qb * 32 + l3 + 8 * tq + 4 * hq);
-          hmine[tq] = o2_hash64(seed, ((bh * L + qg) * (uint64_t)L + (uint64_t)krow) >> 2);
+          const uint64_t rowi = bh * (uint64_t)L + (uint64_t)(t * 64 + qb * 32 + l3 + 8 * tq + 4 * hq);
+          hmine[tq] = o2_hash64(seed, rowi * (uint64_t)lq + (uint64_t)(krow >> 2));
         }
       }
       const int kbyte = 8 * (krow & 3);
+      // per-row statistics: registers 4g..4g+3 are 4 consecutive query rows -> one 16-byte LDS read each
+      f32x4 lse4[4], dl4[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        lse4[g4] = *reinterpret_cast<const f32x4*>(s_lse + qb * 32 + 8 * g4 + 4 * hq);
+        if (DO_DK) dl4[g4] = *reinterpret_cast<const f32x4*>(s_dlt + qb * 32 + 8 * g4 + 4 * hq);
+      }
       f32x16 pd;  // P after dropout (for dV)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;  // query row of register r
-        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - s_lse[ql]);
+        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse4[r >> 2][r & 3]);
         float dpr = dp[r];
         float pdr = p;
         if (DROP) {
           const uint32_t hh = quad_bcast(hmine[r >> 2], r & 3);
           const bool keep = ((hh >> kbyte) & 0xffu) >= thr;
-          dpr = keep ? dpr * dscale : 0.f;
-          pdr = keep ? p * dscale : 0.f;
+          dpr = keep ? dpr : 0.f;     // dscale is applied once, on the final dK / dV tiles
+          pdr = keep ? p : 0.f;
         }
-        pd[r] = pdr;
-        s[r] = p * (dpr - s_dlt[ql]);  // dS
+        if (DO_DV) pd[r] = pdr;
+        if (DO_DK) s[r] = p * (dpr - dl4[r >> 2][r & 3]);  // dS
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = pack_frag(pd, ss);
-        const bf16x8 dsf = pack_frag(s, ss);
+        if (DO_DV) {
+          const bf16x8 pf = pack_frag(pd, ss);
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db) {
-          dv[db] = MFMA32(tr_frag<D>(sdo, qb * 32 + ss * 16, db, lane), pf, dv[db]);   // dV^T += dO^T . P
-          dk[db] = MFMA32(tr_frag<D>(sq, qb * 32 + ss * 16, db, lane), dsf, dk[db]);   // dK^T += Q^T . dS
+          for (int db = 0; db < C::NDB; ++db)
+            dv[db] = MFMA32(tr_frag<D>(sdo, qb * 32 + ss * 16, db, lane), pf, dv[db]);   // dV^T += dO^T . P
+        }
+        if (DO_DK) {
+          const bf16x8 dsf = pack_frag(s, ss);
+#pragma unroll
+          for (int db = 0; db < C::NDB; ++db)
+            dk[db] = MFMA32(tr_frag<D>(sq, qb * 32 + ss * 16, db, lane), dsf, dk[db]);   // dK^T += Q^T . dS
         }
       }
     }
@@ -478,12 +499,18 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dkv_kernel(c
     for (int g4 = 0; g4 < 4; ++g4) {
       const int dd = db * 32 + 8 * g4 + 4 * hq;
       u32x2 w;
-      w[0] = pack_bf2(dk[db][4 * g4] * scale, dk[db][4 * g4 + 1] * scale);
-      w[1] = pack_bf2(dk[db][4 * g4 + 2] * scale, dk[db][4 * g4 + 3] * scale);
-      *reinterpret_cast<u32x2*>(dkrow + dd) = w;
-      w[0] = pack_bf2(dv[db][4 * g4], dv[db][4 * g4 + 1]);
-      w[1] = pack_bf2(dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
-      *reinterpret_cast<u32x2*>(dvrow + dd) = w;
+      if (DO_DK) {
+        const float fk = DROP ? scale * dscale : scale;
+        w[0] = pack_bf2(dk[db][4 * g4] * fk, dk[db][4 * g4 + 1] * fk);
+        w[1] = pack_bf2(dk[db][4 * g4 + 2] * fk, dk[db][4 * g4 + 3] * fk);
+        *reinterpret_cast<u32x2*>(dkrow + dd) = w;
+      }
+      if (DO_DV) {
+        const float fv = DROP ? dscale : 1.0f;
+        w[0] = pack_bf2(dv[db][4 * g4] * fv, dv[db][4 * g4 + 1] * fv);
+        w[1] = pack_bf2(dv[db][4 * g4 + 2] * fv, dv[db][4 * g4 + 3] * fv);
+        *reinterpret_cast<u32x2*>(dvrow + dd) = w;
+      }
     }
 }
 
@@ -531,16 +558,22 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
                      (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
   O2_CHECK_LAUNCH();
   dim3 grid(L / 128, H, B), block(256);
-#define O2_BWD(DV, DR)                                                                                               \
-  do {                                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout,    \
-                       lse, delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);                                  \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout,   \
-                       lse, delta, (bf16_t*)dqkv, L, H, scale, thr, dscale, seed);                                  \
-  } while (0)
-  if (d == 128) { if (thr) O2_BWD(128, true); else O2_BWD(128, false); }
-  else { if (thr) O2_BWD(64, true); else O2_BWD(64, false); }
-#undef O2_BWD
+  const bf16_t* q_ = (const bf16_t*)qkv;
+  const bf16_t* do_ = (const bf16_t*)dout;
+  bf16_t* dq_ = (bf16_t*)dqkv;
+#define O2_DQ(DV, DR) \
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale, seed)
+#define O2_DKV(DV, DR, W) \
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale, seed)
+  if (d == 128) {
+    if (thr) { O2_DQ(128, true); O2_DKV(128, true, 1); O2_DKV(128, true, 2); }
+    else { O2_DQ(128, false); O2_DKV(128, false, 1); O2_DKV(128, false, 2); }
+  } else {
+    if (thr) { O2_DQ(64, true); O2_DKV(64, true, 0); }
+    else { O2_DQ(64, false); O2_DKV(64, false, 0); }
+  }
+#undef O2_DQ
+#undef O2_DKV
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

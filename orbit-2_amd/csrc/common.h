@@ -42,13 +42,14 @@ __device__ __forceinline__ bf16x4 lds_tr4(const void* lds_addr) {
 // tests/ replicate this function in numpy to build bit-identical masks for the oracle.
 __device__ __host__ __forceinline__ uint32_t o2_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo,
                                                       uint32_t idx_hi) {
-  uint32_t h = idx_lo ^ seed_lo;
-  h *= 0x9E3779B1u;
+  // fold the (rarely non-zero) high words with shifts/adds only, then the two-multiply "lowbias32" finaliser:
+  // v_mul_lo_u32 is quarter-rate on CDNA4, and this hash sits in the attention inner loops
+  const uint32_t t = idx_hi ^ seed_hi;
+  uint32_t h = idx_lo ^ seed_lo ^ ((t << 16) | (t >> 16)) ^ (t + (t << 3));
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
   h ^= h >> 15;
-  h += (idx_hi * 0x85EBCA77u) ^ seed_hi;
-  h *= 0x85EBCA6Bu;
-  h ^= h >> 13;
-  h *= 0xC2B2AE35u;
+  h *= 0x846CA68Bu;
   h ^= h >> 16;
   return h;
 }

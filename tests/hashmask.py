@@ -10,13 +10,13 @@ def o2_hash64(seed: int, idx: np.ndarray) -> np.ndarray:
     seed = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
     s_lo, s_hi = seed & M32, (seed >> np.uint64(32)) & M32
     lo, hi = idx & M32, (idx >> np.uint64(32)) & M32
-    h = (lo ^ s_lo) & M32
-    h = (h * np.uint64(0x9E3779B1)) & M32
+    t = (hi ^ s_hi) & M32
+    rot = ((t << np.uint64(16)) | (t >> np.uint64(16))) & M32
+    h = (lo ^ s_lo ^ rot ^ ((t + (t << np.uint64(3))) & M32)) & M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7FEB352D)) & M32
     h ^= h >> np.uint64(15)
-    h = (h + (((hi * np.uint64(0x85EBCA77)) & M32) ^ s_hi)) & M32
-    h = (h * np.uint64(0x85EBCA6B)) & M32
-    h ^= h >> np.uint64(13)
-    h = (h * np.uint64(0xC2B2AE35)) & M32
+    h = (h * np.uint64(0x846CA68B)) & M32
     h ^= h >> np.uint64(16)
     return h
 
