@@ -322,12 +322,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   // (A: L(kt-1), B: L(kt-1) which ends one barrier before A's L(kt)); fragments of stage kt+1 are read only after
   // every wave's share of that stage has landed (waited for at the end of M(kt-2), >= one barrier earlier).
   // Stages past the end re-load the last K-slab into a dead slot: branch-free loop, constant vmcnt arithmetic.
-  auto issue = [&](int st) {
+  auto issue_a = [&](int st) {
     const int kst = st < nk ? st : nk - 1;
-    char* d = smem + (st & 3) * STAGE2;
-    stage_tile2<A_KC>(A, lda, m0, M, kst * BK2, d, wave, lane);
-    stage_tile2<B_KC>(B, ldb, n0, N, kst * BK2, d + STAGE2 / 2, wave, lane);
+    stage_tile2<A_KC>(A, lda, m0, M, kst * BK2, smem + (st & 3) * STAGE2, wave, lane);
   };
+  auto issue_b = [&](int st) {
+    const int kst = st < nk ? st : nk - 1;
+    stage_tile2<B_KC>(B, ldb, n0, N, kst * BK2, smem + (st & 3) * STAGE2 + STAGE2 / 2, wave, lane);
+  };
+  auto issue = [&](int st) { issue_a(st); issue_b(st); };
   issue(0); issue(1); issue(2); issue(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -342,9 +345,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();            // every wave holds its stage-0 fragments: slot 0 may be refilled
   if (wave >= 4) __builtin_amdgcn_s_barrier();   // stagger the second wave of every SIMD by one phase
+  // The LDS-DMA issue cost (~100-180 cycles each inside a load phase) makes L longer than M when all four
+  // pieces of a stage are issued in L; two of them are therefore issued between the MFMAs of M (phase balance).
 #define O2_RING_STEP(KT, FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                                   \
   {                                                                                                        \
-    issue((KT) + 4);                                                                                       \
+    issue_a((KT) + 4);                                                                                     \
     {                                                                                                      \
       const int nx_ = (KT) + 1 < nk ? (KT) + 1 : nk - 1;                                                   \
       const char* sa_ = smem + (nx_ & 3) * STAGE2;                                                         \
@@ -356,7 +361,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                   \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_CUR[j], FA_CUR[i], acc[i][j], 0, 0, 0);     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    issue_b((KT) + 4);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    _Pragma("unroll") for (int i = 4; i < 8; ++i)                                                          \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_CUR[j], FA_CUR[i], acc[i][j], 0, 0, 0);     \
     __builtin_amdgcn_s_setprio(0);                                                                         \
