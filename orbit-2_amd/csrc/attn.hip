@@ -170,23 +170,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * sc_log2);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale: the reference max m_run only moves when some row of this wave outgrows it by more
+    // than 2^RESCALE_THR (wave-uniform decision), so the O-wide multiply is skipped on almost every tile.
+    // P is then bounded by 2^RESCALE_THR instead of 1; O and l use the same reference, the result is exact.
+    constexpr float RESCALE_THR = 5.0f;
+    const float mt = mx * sc_log2;
+    float alpha = 1.0f;
+    if (__any(mt > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[kb][r] * sc_log2 - m_new);
+        const float p = __builtin_amdgcn_exp2f(s[kb][r] * sc_log2 - m_run);
         s[kb][r] = p;
         psum += p;
       }
     l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < C::NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     if (DROP) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) drop_keys_in_regs(s[kb], seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);

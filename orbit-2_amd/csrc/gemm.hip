@@ -398,18 +398,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------
 // small fp32 GEMM (table algebra; sizes ~ [115 x D] x [D x D]): 64x64 tile, 16x16 threads, 4x4 micro-tile
 // ------------------------------------------------------------------------------------------
+template <int RM>   // block tile = (16*RM) x 64; RM = 4 (64 rows) or 1 (16 rows: skinny-M problems fill the chip)
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                     int ldc, int ta, int tb, float alpha, float beta) {
-  __shared__ float sA[16][64 + 1];
+  constexpr int TMB = 16 * RM;
+  __shared__ float sA[16][TMB + 1];
   __shared__ float sB[16][64 + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
+  const int m0 = blockIdx.y * TMB, n0 = blockIdx.x * 64;
+  float acc[RM][4] = {};
   for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+    for (int e = threadIdx.x; e < 16 * TMB; e += 256) {
       int kk, mm;
-      if (ta) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }
+      if (ta) { mm = e % TMB; kk = e / TMB; } else { kk = e & 15; mm = e >> 4; }
       const int gm = m0 + mm, gk = k0 + kk;
       float v = 0.f;
       if (gm < M && gk < K) v = ta ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
@@ -426,21 +428,21 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      float a[4], b[4];
+      float a[RM], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
+      for (int i = 0; i < RM; ++i) a[i] = sA[kk][ty * RM + i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = sB[kk][tx * 4 + j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
+  for (int i = 0; i < RM; ++i) {
+    const int m = m0 + ty * RM + i;
     if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -531,9 +533,16 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
 extern "C" int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                                 int ldc, int ta, int tb, float alpha, float beta, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return O2_ERR_ARG;
-  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-  hipLaunchKernelGGL(sgemm_kernel, grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
-                     alpha, beta);
+  const long blocks64 = (long)((N + 63) / 64) * ((M + 63) / 64);
+  if (blocks64 >= 512) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+    hipLaunchKernelGGL(sgemm_kernel<4>, grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
+                       alpha, beta);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 15) / 16), block(256);
+    hipLaunchKernelGGL(sgemm_kernel<1>, grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
+                       alpha, beta);
+  }
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

@@ -170,6 +170,24 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
         assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
 
 
+def test_attention_forced_late_rescale(hip):
+    """The forward defers its running-max rescale (csrc/attn.hip RESCALE_THR); force the branch late in the key
+    loop: one key far down the sequence matches every query strongly, so the row max jumps by >> 2^5 there."""
+    B, L, H, d = 1, 512, 2, 128
+    g = torch.Generator().manual_seed(77)
+    qkv = torch.randn(B, L, 3, H, d, generator=g) * 0.5
+    qkv[:, 300, 1] = qkv[:, :, 0].mean(1) * 60 + 3.0        # a key aligned with the mean query, scaled up
+    qkv[:, 450, 1] *= 12.0
+    qkv = rt(qkv.reshape(B, L, 3 * H * d))
+    ref = _attn_ref(qkv, B, L, H, d)
+    out, lse = hip.attn_fwd(bf(qkv).cuda(), B, L, H, d, 0.0, 0)
+    q, k, _ = qkv.view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    sc = (q * d ** -0.5) @ k.transpose(-2, -1)
+    assert float((sc.max(-1).values - sc[..., :256].max(-1).values).max()) > 5.0   # the max really jumps late (> 2^5 in the exp2 domain)
+    assert nerr(out, ref) < 1e-2
+    assert nerr(lse, torch.logsumexp(sc, -1)) < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------
 def _tables(sd, heads, ids, D):
     """fp32 table algebra of the folded variable aggregation (see csrc/varagg.hip header)."""
