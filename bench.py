@@ -37,6 +37,7 @@ MODELS = {  # configs/interm_*.yaml of the reference
     "interm_8m": dict(embed_dim=256, depth=6, num_heads=4),
     "interm_117m": dict(embed_dim=1024, depth=8, num_heads=16),
     "interm_1b": dict(embed_dim=3072, depth=8, num_heads=24),
+    "interm_10b": dict(embed_dim=8192, depth=11, num_heads=32),
 }
 PEAK_BF16 = 2.5e15   # dense MFMA peak, MI355X_MICROARCH.md
 METRIC = "climate-grid samples/sec/node (fwd+bwd), interm_1b ERA5 1.4°→0.25°, 1/2/4/8 GPUs"

@@ -28,10 +28,11 @@ template <int D> struct Cfg {
   static constexpr int NDB = D / 32;           // 32-wide blocks of the head dim
 };
 
+// XOR applied to the 16-byte chunk index of a row (only its low 4 bits, i.e. within one 256-byte bank line)
 template <int D>
 __device__ __forceinline__ int swz(int row) {
-  if (D == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
-  else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  if (D >= 128) return ((row & 3) << 2) | ((row >> 2) & 3);     // rows are 1 (d=128) or 2 (d=256) bank lines
+  else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);        // d=64: two rows share a bank line
 }
 
 // stage a [64 rows][D] tile; rows are tokens tok0..tok0+63 of one head: src(row) = base + row*stride
@@ -110,7 +111,7 @@ __device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint
 // forward
 // =============================================================================================
 template <int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
                                                           unsigned thr, float dscale, uint64_t seed) {
   using C = Cfg<D>;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // backward, dQ: same geometry as the forward (query on the lane)
 // =============================================================================================
 template <int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                              const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // At d = 128 the fused form needs 236 VGPR + 160 AGPR (1 wave/SIMD, measured 576 TFLOP/s executed); split in two
 // passes (5 MFMA products instead of 4) each pass fits 2 waves/SIMD.
 template <int D, bool DROP, int WHICH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 static int attn_check(const void* a, const void* b, int B, int L, int H, int d, float p) {
   if (!a || !b || B <= 0 || L <= 0 || H <= 0) return O2_ERR_ARG;
-  if (d != 64 && d != 128) return O2_ERR_UNSUPPORTED;
+  if (d != 64 && d != 128 && d != 256) return O2_ERR_UNSUPPORTED;
   if (L % 128) return O2_ERR_ARG;
   if (p < 0.f || p >= 1.f) return O2_ERR_ARG;
   return O2_OK;
@@ -545,7 +546,8 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
 #define O2_FWD(DV, DR)                                                                                              \
   hipLaunchKernelGGL((attn_fwd_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H,   \
                      sc_log2, thr, dscale, seed)
-  if (d == 128) { if (thr) O2_FWD(128, true); else O2_FWD(128, false); }
+  if (d == 256) { if (thr) O2_FWD(256, true); else O2_FWD(256, false); }
+  else if (d == 128) { if (thr) O2_FWD(128, true); else O2_FWD(128, false); }
   else { if (thr) O2_FWD(64, true); else O2_FWD(64, false); }
 #undef O2_FWD
   O2_CHECK_LAUNCH();
@@ -573,7 +575,10 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale, seed)
 #define O2_DKV(DV, DR, W) \
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale, seed)
-  if (d == 128) {
+  if (d == 256) {
+    if (thr) { O2_DQ(256, true); O2_DKV(256, true, 1); O2_DKV(256, true, 2); }
+    else { O2_DQ(256, false); O2_DKV(256, false, 1); O2_DKV(256, false, 2); }
+  } else if (d == 128) {
     if (thr) { O2_DQ(128, true); O2_DKV(128, true, 1); O2_DKV(128, true, 2); }
     else { O2_DQ(128, false); O2_DKV(128, false, 1); O2_DKV(128, false, 2); }
   } else {

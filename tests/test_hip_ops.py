@@ -144,7 +144,7 @@ def _attn_ref(qkv, B, L, H, d, mask=None, sc=1.0):
     return (a @ v).transpose(1, 2).reshape(B, L, H * d)
 
 
-@pytest.mark.parametrize("d,H,L,B", [(64, 2, 128, 2), (128, 2, 256, 1), (64, 4, 512, 1), (128, 3, 384, 2)])
+@pytest.mark.parametrize("d,H,L,B", [(64, 2, 128, 2), (128, 2, 256, 1), (64, 4, 512, 1), (128, 3, 384, 2), (256, 2, 128, 1), (256, 1, 256, 2)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attention_fwd_bwd(hip, d, H, L, B, p):
     g = torch.Generator().manual_seed(d + L)

@@ -14,7 +14,7 @@ def t(f, n=5):
     return e0.elapsed_time(e1) / n
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-for (H, L, d) in [(24, 8192, 128), (16, 512 * 8, 64)]:
+for (H, L, d) in [(24, 8192, 128), (16, 512 * 8, 64), (32, 8192, 256)]:
     qkv = torch.randn(B, L, 3 * H * d, device="cuda").to(torch.bfloat16)
     do = torch.randn(B, L, H * d, device="cuda").to(torch.bfloat16)
     for p in (0.0, 0.1):
