@@ -127,9 +127,9 @@ int orbit2_conv3x3_bwd(const float* dout, const float* in, const int* chan_idx, 
 int orbit2_clamp_channel(float* img, int B, int C, int HW, int chan, void* stream);
 int orbit2_clamp_channel_bwd(const float* img_clamped, float* dimg, int B, int C, int HW, int chan, void* stream);
 
-/* ---- losses (metrics/functional.py:117-202): kind 0 = mse, 1 = bayesian_tv -------------------
+/* ---- losses (metrics/functional.py:59-202): kind 0 = mse, 1 = bayesian_tv, 2 = image_gradient ------
  * pred fp32 [B,C,H,W]; target fp32 [B,C,Ht,Wt] (top-left crop used); lat_w fp32 [H] or NULL;
- * chan_w fp32 [C] or NULL.  out: fp32 [C+1] (per-channel means, aggregate mean). ws fp32 >= (C+1)*1024 */
+ * chan_w fp32 [C] or NULL.  out: fp32 [C+1] (per-channel means, aggregate mean). ws fp32 >= 2*B*C*64 */
 int orbit2_loss_fwd(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, const float* chan_w,
                     float* out, float* ws, int B, int C, int H, int W, int kind, void* stream);
 /* dpred = gscale[0] * d(aggregate)/dpred */

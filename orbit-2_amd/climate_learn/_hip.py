@@ -339,7 +339,7 @@ def loss_fwd(pred, target, lat_w, chan_w, kind):
     B, Cc, H, W = pred.shape
     Ht, Wt = target.shape[2], target.shape[3]
     out = torch.empty(Cc + 1, dtype=F32, device=pred.device)
-    ws = torch.empty((Cc * B + 1) * 64, dtype=F32, device=pred.device)
+    ws = torch.empty(2 * Cc * B * 64, dtype=F32, device=pred.device)
     _chk(lib().orbit2_loss_fwd(_p(pred), _p(target), Ht, Wt, _p(lat_w), _p(chan_w), _p(out), _p(ws), B, Cc, H, W, kind,
                                _stream()), "orbit2_loss_fwd")
     return out

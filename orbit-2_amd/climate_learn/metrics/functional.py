@@ -40,3 +40,10 @@ def mse(pred, target, var_names: Optional[List[str]] = None, var_weights: Option
 def bayesian_tv(pred, target, var_names: Optional[List[str]] = None, var_weights: Optional[Dict[str, float]] = None,
                 aggregate_only: bool = False, lat_weights=None):
     return _fused(pred, target, var_names, var_weights, aggregate_only, lat_weights, 1)
+
+
+def image_gradient(pred, target, var_names: Optional[List[str]] = None, var_weights: Optional[Dict[str, float]] = None,
+                   aggregate_only: bool = False, lat_weights=None):
+    """mean((pred-target)^2 * w_var) + 0.1 * mean(|grad(target) - grad(pred)|) * mean(w_var)  (reference :59-114;
+    forward-difference gradients as torchmetrics.functional.image.image_gradients defines them).  Scalar."""
+    return _fused(pred, target, var_names, var_weights, True, None, 2)

@@ -7,7 +7,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .functional import bayesian_tv, mse
+from .functional import bayesian_tv, image_gradient, mse
 from .utils import MetricsMetaInfo, register
 
 
@@ -44,6 +44,13 @@ class Bayesian_TV(Metric):
         return bayesian_tv(pred, target, var_names, var_weights, self.aggregate_only)
 
 
+@register("imagegradient")
+class IMAGEGRADIENT(Metric):
+    def __call__(self, pred, target, var_names: Optional[List[str]] = None,
+                 var_weights: Optional[Dict[str, float]] = None):
+        return image_gradient(pred, target, var_names, var_weights)
+
+
 @register("lat_mse")
 class LatWeightedMSE(LatitudeWeightedMetric):
     def __call__(self, pred, target, var_names: Optional[List[str]] = None,
@@ -61,5 +68,5 @@ def _not_on_path(name):
     return register(name)(_M)
 
 
-for _n in ("rmse", "pearson", "mean_bias", "mae", "lat_rmse", "lat_acc", "acc", "imagegradient", "perceptual"):
+for _n in ("rmse", "pearson", "mean_bias", "mae", "lat_rmse", "lat_acc", "acc", "perceptual"):
     _not_on_path(_n)

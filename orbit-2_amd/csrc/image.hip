@@ -213,18 +213,23 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                        int Ht, int Wt, const float* __restrict__ latw,
                                                        const float* __restrict__ chanw, float* __restrict__ part,
-                                                       int C, int H, int W, int kind) {
+                                                       float* __restrict__ part2, int C, int H, int W, int kind) {
   const int plane = blockIdx.y;  // b*C + c
   const int c = plane % C, b = plane / C;
   const float* p = pred + (size_t)plane * H * W;
   const float* t = tgt + ((size_t)b * C + c) * Ht * Wt;
   const float cw = chanw ? chanw[c] : 1.f;
-  float s = 0.f;
+  float s = 0.f, s2 = 0.f;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
     const int i = e / W, j = e - i * W;
     const float pv = p[e];
-    const float d = pv - t[(size_t)i * Wt + j];
+    const float tv0 = t[(size_t)i * Wt + j];
+    const float d = pv - tv0;
     float err = d * d;
+    if (kind == 2) {   // image-gradient term (metrics/functional.py:59-114): forward differences, last row/col zero
+      if (j < W - 1) s2 += fabsf((t[(size_t)i * Wt + j + 1] - tv0) - (p[e + 1] - pv));
+      if (i < H - 1) s2 += fabsf((t[(size_t)(i + 1) * Wt + j] - tv0) - (p[e + W] - pv));
+    }
     if (kind == 1) {
       float tv = 0.f;
       if (i < H - 1) {
@@ -238,14 +243,18 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
     s += err * (latw ? latw[i] : 1.f) * cw;
   }
   s = wave_sum(s);
-  __shared__ float sw[4];
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  s2 = wave_sum(s2);
+  __shared__ float sw[8];
+  if ((threadIdx.x & 63) == 0) { sw[threadIdx.x >> 6] = s; sw[4 + (threadIdx.x >> 6)] = s2; }
   __syncthreads();
-  if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+  if (threadIdx.x == 0) {
+    part[(size_t)plane * gridDim.x + blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+    part2[(size_t)plane * gridDim.x + blockIdx.x] = sw[4] + sw[5] + sw[6] + sw[7];
+  }
 }
 
-__global__ void loss_final_kernel(const float* __restrict__ part, int nblk, int B, int C, int HW,
-                                  float* __restrict__ out) {
+__global__ void loss_final_kernel(const float* __restrict__ part, const float* __restrict__ part2, int nblk, int B,
+                                  int C, int HW, const float* __restrict__ chanw, int kind, float* __restrict__ out) {
   // one wave; out[c] = mean over (b, pixels) of channel c; out[C] = mean over everything
   float tot = 0.f;
   for (int c = 0; c < C; ++c) {
@@ -258,7 +267,16 @@ __global__ void loss_final_kernel(const float* __restrict__ part, int nblk, int 
     if (threadIdx.x == 0) out[c] = s / ((float)B * (float)HW);
     tot += s;
   }
-  if (threadIdx.x == 0) out[C] = tot / ((float)B * (float)C * (float)HW);
+  float agg = tot / ((float)B * (float)C * (float)HW);
+  if (kind == 2) {   // + 0.1 * mean(|grad diff|) * mean(channel weights)
+    float s2 = 0.f;
+    for (int e = threadIdx.x; e < B * C * nblk; e += 64) s2 += part2[e];
+    s2 = wave_sum(s2);
+    float cwm = 1.f;
+    if (chanw) { cwm = 0.f; for (int c = 0; c < C; ++c) cwm += chanw[c]; cwm /= (float)C; }
+    agg += 0.1f * (s2 / ((float)B * (float)C * (float)HW)) * cwm;
+  }
+  if (threadIdx.x == 0) out[C] = agg;
 }
 
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
@@ -280,6 +298,19 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     const float wi = latw ? latw[i] : 1.f;
     const float wim = (latw && i > 0) ? latw[i - 1] : 1.f;
     float g = 2.f * (pv - tgt[(((size_t)b * C + c) * Ht + i) * Wt + j]) * wi;
+    if (kind == 2) {
+      const float* t = tgt + ((size_t)b * C + c) * Ht * Wt;
+      const float tv0 = t[(size_t)i * Wt + j];
+      float gs = 0.f;
+      if (j < W - 1) gs += sgn((t[(size_t)i * Wt + j + 1] - tv0) - (p[o + 1] - pv));
+      if (j > 0) gs -= sgn((tv0 - t[(size_t)i * Wt + j - 1]) - (pv - p[o - 1]));
+      if (i < H - 1) gs += sgn((t[(size_t)(i + 1) * Wt + j] - tv0) - (p[o + W] - pv));
+      if (i > 0) gs -= sgn((tv0 - t[(size_t)(i - 1) * Wt + j]) - (pv - p[o - W]));
+      float cwm = 1.f;
+      if (chanw) { cwm = 0.f; for (int cc = 0; cc < C; ++cc) cwm += chanw[cc]; cwm /= (float)C; }
+      dpred[e] = (g * (chanw ? chanw[c] : 1.f) + 0.1f * cwm * gs) * g0;
+      continue;
+    }
     if (kind == 1) {
       float tv = 0.f;
       // terms stored at row i (weight wi) in which p[i][j] is the subtrahend
@@ -379,12 +410,13 @@ extern "C" int orbit2_loss_fwd(const float* pred, const float* target, int Ht, i
                                const float* chan_w, float* out, float* ws, int B, int C, int H, int W, int kind,
                                void* stream) {
   if (!pred || !target || !out || !ws || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ht < H || Wt < W) return O2_ERR_ARG;
-  if (kind != 0 && kind != 1) return O2_ERR_ARG;
+  if (kind < 0 || kind > 2) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  float* ws2 = ws + (size_t)B * C * LOSS_NBLK;
   hipLaunchKernelGGL(loss_fwd_kernel, dim3(LOSS_NBLK, B * C), dim3(256), 0, s, pred, target, Ht, Wt, lat_w, chan_w, ws,
-                     C, H, W, kind);
+                     ws2, C, H, W, kind);
   O2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, ws, LOSS_NBLK, B, C, H * W, out);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, ws, ws2, LOSS_NBLK, B, C, H * W, chan_w, kind, out);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
@@ -394,7 +426,7 @@ extern "C" int orbit2_loss_bwd(const float* pred, const float* target, int Ht, i
                                int kind, void* stream) {
   if (!pred || !target || !gscale || !dpred || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ht < H || Wt < W)
     return O2_ERR_ARG;
-  if (kind != 0 && kind != 1) return O2_ERR_ARG;
+  if (kind < 0 || kind > 2) return O2_ERR_ARG;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((int64_t)B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                      pred, target, Ht, Wt, lat_w, chan_w, gscale, dpred, B, C, H, W, kind);
   O2_CHECK_LAUNCH();

@@ -306,6 +306,22 @@ def test_loss(hip, kind, lat):
     assert nerr(dp, pred.grad) < 2e-5
 
 
+def test_loss_image_gradient(hip):
+    g = torch.Generator().manual_seed(14)
+    B, C, H, W = 2, 3, 20, 36
+    pred = torch.randn(B, C, H, W, generator=g).requires_grad_()
+    tgt = torch.randn(B, C, H + 2, W + 4, generator=g)
+    names = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+    vw = {"2m_temperature_min": 10.0, "2m_temperature_max": 10.0}
+    ref = O.image_gradient(pred, O.crop_target(tgt, pred).contiguous(), names, vw)
+    ref.backward()
+    cw = torch.tensor([1.0, 10.0, 10.0]).cuda()
+    out = hip.loss_fwd(pred.detach().cuda(), tgt.cuda(), None, cw, 2)
+    assert abs(float(out[-1]) - float(ref)) / float(ref) < 2e-5
+    dp = hip.loss_bwd(pred.detach().cuda(), tgt.cuda(), None, cw, torch.ones(1, device="cuda"), 2)
+    assert nerr(dp, pred.grad) < 2e-5
+
+
 def test_clamp_channel(hip):
     g = torch.Generator().manual_seed(8)
     x = torch.randn(2, 3, 8, 8, generator=g)

@@ -89,3 +89,20 @@ def test_hash_replica_known_answers():
     assert h.dtype == np.uint64 and len(set(h.tolist())) == 3
     m, sc = keep_mask(7, 1 << 16, 0.1)
     assert abs(m.mean() - (1 - 26 / 256)) < 5e-3 and abs(sc - 256 / 230) < 1e-12
+
+
+def test_checkpoint_pos_embed_interpolation_matches_oracle():
+    """interpolate_pos_embed (reference components/pos_embed.py:75-100) on a checkpoint dict, vs the oracle."""
+    from types import SimpleNamespace
+    from climate_learn.models.hub.components.pos_embed import interpolate_pos_embed, interpolate_pos_embed_on_the_fly
+    from oracle import orbit2_oracle as O
+    g = torch.Generator().manual_seed(5)
+    pe = torch.randn(1, 4 * 8, 64, generator=g)
+    ck = {"pos_embed": pe.clone()}
+    interpolate_pos_embed(SimpleNamespace(patch_size=2), ck, new_size=(16, 32))
+    ref = O.pos_embed_for_grid(pe, 2, (16, 32))
+    assert ck["pos_embed"].shape == (1, 8 * 16, 64) and torch.allclose(ck["pos_embed"], ref, atol=1e-6)
+    assert torch.allclose(interpolate_pos_embed_on_the_fly(pe, 2, (16, 32)), ref, atol=1e-6)
+    same = {"pos_embed": pe.clone()}
+    interpolate_pos_embed(SimpleNamespace(patch_size=2), same, new_size=(8, 16))
+    assert torch.equal(same["pos_embed"], pe)

@@ -148,3 +148,50 @@ def test_train_mode_dropout_and_recompute_match():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_checkpoint_roundtrip_resumes_identically(tmp_path):
+    """Reference checkpoint format (examples/intermediate_downscaling.py:775-795): {'epoch','model_state_dict',
+    'optimizer_state_dict','scheduler_state_dict'}; resuming from it reproduces the uninterrupted run."""
+    import climate_learn as cl
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.testing import build_pair
+    from climate_learn.trainer import training_step
+    dev = torch.device("cuda")
+    loss_fn = Bayesian_TV(True)
+
+    def make():
+        model, sd, cfg, O, x, y, iv, ov = build_pair(D=128, depth=1, heads=2, seed=3)
+        model = model.cuda().eval()
+        eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential))
+        opt = cl.load_optimizer(eng, "adamw", {"lr": 1e-3, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+        sch = cl.load_lr_scheduler("linear-warmup-cosine-annealing", opt,
+                                   {"warmup_epochs": 2, "max_epochs": 10, "warmup_start_lr": 1e-5, "eta_min": 1e-6})
+        return eng, opt, sch, (x, y, iv, ov)
+
+    def step(eng, opt, batch):
+        loss = training_step(batch, 0, eng, dev, None, loss_fn)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    eng, opt, sch, batch = make()
+    a = [step(eng, opt, batch) for _ in range(2)]
+    sch.step()
+    path = str(tmp_path / "interm_epoch_0.ckpt")
+    torch.save({"epoch": 0, "model_state_dict": eng.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                "scheduler_state_dict": sch.state_dict()}, path)
+    a += [step(eng, opt, batch) for _ in range(2)]
+
+    eng2, opt2, sch2, _ = make()
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"}
+    assert all(v.dtype == torch.float32 for v in ck["model_state_dict"].values())
+    eng2.load_state_dict(ck["model_state_dict"])
+    opt2.load_state_dict(ck["optimizer_state_dict"])
+    sch2.load_state_dict(ck["scheduler_state_dict"])
+    b = [step(eng2, opt2, batch) for _ in range(2)]
+    assert a[2:] == b, (a, b)          # bit-identical continuation (deterministic kernels, same lr, same moments)
+    assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
