@@ -112,8 +112,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force = os.environ.get("ORBIT2_FORCE_COLLECTIVES", "0") == "1"
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import climate_learn as cl
@@ -166,7 +168,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -230,7 +232,7 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(a.model, V, C)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

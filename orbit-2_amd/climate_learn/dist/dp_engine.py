@@ -65,6 +65,10 @@ class HipDataParallel(nn.Module):
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # ORBIT2_FORCE_COLLECTIVES=1 issues the bucket all-reduces even on a single rank (exercises the RCCL path
+        # -- streams, async handles, bf16 reduction -- on a 1-GPU box)
+        import os as _os
+        self.force_comm = dist.is_initialized() and _os.environ.get("ORBIT2_FORCE_COLLECTIVES", "0") == "1"
         self.overlap = overlap
         params = [p for p in module.parameters()]
         assert params, "module has no parameters"
@@ -136,7 +140,7 @@ class HipDataParallel(nn.Module):
                 bk.grad_views.append(self.g32[sg:og32])
             self.buckets.append(bk)
         self.refresh_compute_copies()
-        if sync_module_states and self.world > 1:
+        if sync_module_states and (self.world > 1 or self.force_comm):
             dist.broadcast(self.flat32, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0,
                            group=self.pg)
             self.refresh_compute_copies()
@@ -188,7 +192,7 @@ class HipDataParallel(nn.Module):
 
     def _launch(self, bk: Bucket):
         self._launched.append(bk)
-        if self.world == 1:
+        if self.world == 1 and not self.force_comm:
             return
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
@@ -207,7 +211,7 @@ class HipDataParallel(nn.Module):
         for bk in self.buckets:
             if bk not in self._launched and bk.pending != sum(1 for p in bk.params if p.requires_grad):
                 self._launch(bk)      # partially-ready unit: reduce what is there
-            elif bk not in self._launched and self.world > 1:
+            elif bk not in self._launched and (self.world > 1 or self.force_comm):
                 self._launch(bk)      # untouched unit still has to take part in the collective
         for bk in self._launched:
             if bk.handle:
