@@ -80,22 +80,88 @@ class SyntheticGridDataModule:
 
 
 class IterDataModule(SyntheticGridDataModule):
-    """Reference keyword surface (itermodule.py:33-56).  *_dir arguments name datasets that do not exist in
-    this environment; `lowres_hw` / `highres_hw` (or the defaults of the named resolution) size the synthetic
-    grids instead."""
+    """Reference keyword surface (itermodule.py:33-56).
+
+    * `inp_root_dir` / `out_root_dir` that exist on disk -> the npz data plane (climate_learn.data.iterdataset):
+      shards <root>/{train,val,test}/*.npz, lat.npy / lon.npy, normalize_{mean,std}.npz, <split>/climatology.npz,
+      per-rank x per-worker file sharding, div x div tiling with overlap halo, normalisation, shuffle buffer.
+    * otherwise -> seeded synthetic grids of `lowres_hw` / `highres_hw` (tiled with the same arithmetic)."""
 
     def __init__(self, task="downscaling", inp_root_dir=None, out_root_dir=None, in_vars=None, out_vars=None,
                  data_par_size=1, data_par_group=None, src=None, history=1, window=6, pred_range=6, subsample=1,
                  batch_size=64, buffer_size=10000, num_workers=0, pin_memory=False, div=1, overlap=0,
                  lowres_hw=(32, 64), highres_hw=None, steps_per_epoch=4, seed=0):
+        import os
+        from . import iterdataset as ID
         if task != "downscaling":
             raise NotImplementedError("only the downscaling task is on the hot path")
         rank = 0
         if data_par_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             rank = torch.distributed.get_rank(group=data_par_group)
-        if div > 1:   # spatial tiling: every sample is a 1/div x 1/div tile (+ overlap halo), iterdataset.py:112-170
-            lowres_hw = (lowres_hw[0] // div + 2 * (overlap // 2), lowres_hw[1] // div + 2 * overlap)
-            lowres_hw = (lowres_hw[0] // 2 * 2, lowres_hw[1] // 2 * 2)
-            highres_hw = None
+        self.inp_root_dir, self.out_root_dir = inp_root_dir, out_root_dir
+        self.data_par_size, self.data_par_group = data_par_size, data_par_group
+        self.subsample, self.buffer_size, self.num_workers = subsample, buffer_size, num_workers
+        self.div, self.overlap = div, overlap
+        self.on_disk = bool(inp_root_dir) and os.path.isdir(os.path.join(str(inp_root_dir), "train"))
+        if self.on_disk:
+            lat_lo = np.load(os.path.join(inp_root_dir, "lat.npy"))
+            lon_lo = np.load(os.path.join(inp_root_dir, "lon.npy"))
+            lat_hi = np.load(os.path.join(out_root_dir, "lat.npy"))
+            lon_hi = np.load(os.path.join(out_root_dir, "lon.npy"))
+            lowres_hw, highres_hw = (len(lat_lo), len(lon_lo)), (len(lat_hi), len(lon_hi))
+            self._full_lat, self._full_lon = lat_hi, lon_hi
         highres_hw = highres_hw or (lowres_hw[0] * 4, lowres_hw[1] * 4)
-        super().__init__(in_vars, out_vars or in_vars, lowres_hw, highres_hw, batch_size, steps_per_epoch, seed, rank)
+        lo, hi = ID.tile_dims(lowres_hw[0], lowres_hw[1], highres_hw[0], highres_hw[1], div, overlap)
+        super().__init__(in_vars, out_vars or in_vars, lo, hi, batch_size, steps_per_epoch, seed, rank)
+
+    # ---- on-disk mode ---------------------------------------------------------------------------------------
+    def _files(self, root, split):
+        import glob
+        import os
+        return sorted(f for f in glob.glob(os.path.join(root, split, "*.npz")) if "climatology" not in f)
+
+    def _normalizers(self, root, variables):
+        import os
+        from . import iterdataset as ID
+        from .processing.era5_constants import PRECIP_VARIABLES
+        mean = dict(np.load(os.path.join(root, "normalize_mean.npz")))
+        std = dict(np.load(os.path.join(root, "normalize_std.npz")))
+        return {v: (ID.LogTransform() if v in PRECIP_VARIABLES else ID.Normalize(mean[v][0], std[v][0])) for v in variables}
+
+    def setup(self, stage=None):
+        if not self.on_disk:
+            return super().setup(stage)
+        self.lat, self.lon = self._full_lat, self._full_lon
+        self.transforms = self._normalizers(self.inp_root_dir, self.in_vars)
+        self.output_transforms = self._normalizers(self.out_root_dir, self.out_vars)
+        self._ready = True
+
+    def get_out_transforms(self):
+        return dict(self.output_transforms) if self.on_disk else super().get_out_transforms()
+
+    def get_climatology(self, split="val"):
+        if not self.on_disk:
+            return super().get_climatology(split)
+        import os
+        clim = np.load(os.path.join(self.out_root_dir, split, "climatology.npz"))
+        return {v: torch.from_numpy(np.squeeze(clim[v].astype(np.float32), axis=0)) for v in self.out_vars}
+
+    def _loader(self, split, shuffle):
+        from torch.utils.data import DataLoader
+        from . import iterdataset as ID
+        rd = ID.NpyReader(self._files(self.inp_root_dir, split), self._files(self.out_root_dir, split), self.in_vars,
+                          self.out_vars, data_par_size=self.data_par_size, data_par_group=self.data_par_group,
+                          shuffle=shuffle, div=self.div, overlap=self.overlap)
+        ds = ID.IndividualDataIter(ID.Downscale(rd), self.transforms, self.output_transforms, subsample=self.subsample)
+        if shuffle and self.buffer_size > 0:
+            ds = ID.ShuffleIterableDataset(ds, self.buffer_size)
+        return DataLoader(ds, batch_size=self.batch_size, drop_last=False, num_workers=self.num_workers,
+                          collate_fn=ID.collate_fn)
+
+    def train_dataloader(self):
+        return self._loader("train", True) if self.on_disk else super().train_dataloader()
+
+    def val_dataloader(self):
+        return self._loader("val", False) if self.on_disk else super().val_dataloader()
+
+    test_dataloader = val_dataloader

@@ -16,8 +16,10 @@ path touches are stubbed with their documented behaviour:
 Usage:  python tests/golden/make_golden.py          (writes tests/golden/*.npz)
 """
 import importlib
+import importlib.util
 import os
 import sys
+import tempfile
 import types
 
 import numpy as np
@@ -345,6 +347,32 @@ def main():
         opt2.step()
         sc2.step()
     np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), lr_w2_m100=np.array(lrs), lr_w5_m30=np.array(lrs2))
+
+    # ------------------------------------------------------------------ NpyReader tiling / sharding (data plane)
+    spec = importlib.util.spec_from_file_location("ref_iterdataset", REF + "/data/iterdataset.py")
+    rid = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rid)
+    tg = {}
+    with tempfile.TemporaryDirectory() as td:
+        files_in, files_out = [], []
+        for f in range(3):
+            yy, xx = np.meshgrid(np.arange(16), np.arange(32), indexing="ij")
+            lo = (f * 1e6 + yy * 1000 + xx).astype(np.float64)[None, None].repeat(2, 0)          # [T=2,1,16,32]
+            YY, XX = np.meshgrid(np.arange(64), np.arange(128), indexing="ij")
+            hi = (f * 1e6 + YY * 1000 + XX).astype(np.float64)[None, None].repeat(2, 0)          # [2,1,64,128]
+            pi, po = os.path.join(td, "in_%d.npz" % f), os.path.join(td, "out_%d.npz" % f)
+            np.savez(pi, a=lo, b=lo + 0.5)
+            np.savez(po, c=hi)
+            files_in.append(pi)
+            files_out.append(po)
+        for div, ov in ((1, 0), (2, 2), (4, 3), (2, 1)):
+            rd = rid.NpyReader(files_in, files_out, ["a", "b"], ["c"], data_par_size=1, div=div, overlap=ov)
+            rec = []
+            for xin, yout, _, _ in rd:
+                a, c = xin["a"], yout["c"]
+                rec.append([a.shape[1], a.shape[2], a[0, 0, 0], a[0, -1, -1], c.shape[1], c.shape[2], c[0, 0, 0], c[0, -1, -1]])
+            tg["tiles_div%d_ov%d" % (div, ov)] = np.array(rec, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "tiling.npz"), **tg)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
