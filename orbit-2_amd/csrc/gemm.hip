@@ -314,13 +314,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   const int nk = K / BK2;
   // Ring protocol (4 slots of one 32-deep K-slab each), two barriers per K-slab, the two waves of every SIMD
   // (wave w and w+4) STAGGERED by one barrier so that one of them issues MFMAs while the other one loads:
-  //   L(kt): refill the slot of stage kt with stage kt+4 (LDS-DMA), read the fragments of stage kt+1 into the
-  //          spare register set, lgkmcnt(0)
-  //   M(kt): 32 MFMAs on the fragments of stage kt; counted vmcnt(4): stage kt+3 has landed, kt+4 stays in flight
+  //   L(kt): refill the slot of stage kt-1 with stage kt+3 (LDS-DMA; half of the pieces are issued between the
+  //          MFMAs of M to balance the two phases), read the 12 fragments of stage kt, lgkmcnt(0)
+  //   M(kt): 32 MFMAs; counted vmcnt(4): stage kt+2 has landed, stage kt+3 stays in flight
   //   A (waves 0-3):  L(0) | M(0) | L(1) | M(1) | ...        B (waves 4-7):  -- | L(0) | M(0) | L(1) | ...
-  // Hazards (| = s_barrier): a slot is refilled in L(kt) only after every wave has read stage kt's fragments
-  // (A: L(kt-1), B: L(kt-1) which ends one barrier before A's L(kt)); fragments of stage kt+1 are read only after
-  // every wave's share of that stage has landed (waited for at the end of M(kt-2), >= one barrier earlier).
+  // Hazards (| = s_barrier).  WAR: slot (kt-1)&3 is refilled in L(kt)/M(kt); its last readers are A's L(kt-1) and
+  // B's L(kt-1) (concurrent with A's M(kt-1)), both at least one barrier earlier.  RAW: stage kt is read in L(kt);
+  // every wave waited for its share of it at the end of its M(kt-2), B's M(kt-2) being concurrent with A's
+  // L(kt-1), i.e. one barrier before A's L(kt).
   // Stages past the end re-load the last K-slab into a dead slot: branch-free loop, constant vmcnt arithmetic.
   auto issue_a = [&](int st) {
     const int kst = st < nk ? st : nk - 1;
@@ -330,57 +331,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     const int kst = st < nk ? st : nk - 1;
     stage_tile2<B_KC>(B, ldb, n0, N, kst * BK2, smem + (st & 3) * STAGE2 + STAGE2 / 2, wave, lane);
   };
-  auto issue = [&](int st) { issue_a(st); issue_b(st); };
-  issue(0); issue(1); issue(2); issue(3);
+  issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2); issue_b(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
-  {
-    const char* sa = smem;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb0[j] = read_frag2<B_KC>(sa + STAGE2 / 2, wn * 64 + j * 16, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa0[i] = read_frag2<A_KC>(sa, wm * 128 + i * 16, lane);
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();            // every wave holds its stage-0 fragments: slot 0 may be refilled
   if (wave >= 4) __builtin_amdgcn_s_barrier();   // stagger the second wave of every SIMD by one phase
-  // The LDS-DMA issue cost (~100-180 cycles each inside a load phase) makes L longer than M when all four
-  // pieces of a stage are issued in L; two of them are therefore issued between the MFMAs of M (phase balance).
-#define O2_RING_STEP(KT, FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                                   \
-  {                                                                                                        \
-    issue_a((KT) + 4);                                                                                     \
-    {                                                                                                      \
-      const int nx_ = (KT) + 1 < nk ? (KT) + 1 : nk - 1;                                                   \
-      const char* sa_ = smem + (nx_ & 3) * STAGE2;                                                         \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-          FB_NXT[j] = read_frag2<B_KC>(sa_ + STAGE2 / 2, wn * 64 + j * 16, lane);                          \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
-          FA_NXT[i] = read_frag2<A_KC>(sa_, wm * 128 + i * 16, lane);                                      \
-    }                                                                                                      \
-    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                   \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    __builtin_amdgcn_s_setprio(1);                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_CUR[j], FA_CUR[i], acc[i][j], 0, 0, 0);     \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    issue_b((KT) + 4);                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    _Pragma("unroll") for (int i = 4; i < 8; ++i)                                                          \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_CUR[j], FA_CUR[i], acc[i][j], 0, 0, 0);     \
-    __builtin_amdgcn_s_setprio(0);                                                                         \
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                       \
-    __builtin_amdgcn_s_barrier();                                                                          \
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sa = smem + (kt & 3) * STAGE2;
+    const char* sb = sa + STAGE2 / 2;
+    bf16x8 fa[8], fb[4];
+    issue_a(kt + 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = read_frag2<B_KC>(sb, wn * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = read_frag2<A_KC>(sa, wm * 128 + i * 16, lane);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_b(kt + 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 4; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    O2_RING_STEP(kt, fa0, fb0, fa1, fb1)
-    O2_RING_STEP(kt + 1, fa1, fb1, fa0, fb0)
-  }
-  if (kt < nk) O2_RING_STEP(kt, fa0, fb0, fa1, fb1)
-#undef O2_RING_STEP
   if (wave < 4) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
 
