@@ -187,7 +187,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss_val = float(last)
+    loss_val = float(last.detach())
 
     if rank == 0:
         sps = world * B * a.steps / dt
