@@ -215,7 +215,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "algorithmic_bytes_per_launch": gm.get("bytes", None),
-                         "kernel": "gemm128_kernel (orbit2_gemm_bf16)", "launches": gm["launches"],
+                         "kernel": "orbit2_gemm_bf16 = gemm256_kernel (NT ring) + gemm128_kernel (K-strided forms), all launches of the timed region", "launches": gm["launches"],
                          "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
             "step_model": {
                 "model_flops_per_sample_dense": 3 * f_dense, "executed_flops_per_sample_folded_varagg": 3 * f_exec,
