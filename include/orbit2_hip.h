@@ -68,7 +68,7 @@ int orbit2_layernorm_bwd_ws_floats(int rows, int D);
 
 /* ---- multi-head self-attention core (attention.py:54-78): softmax(q k^T / sqrt(d)) v --------
  * qkv: bf16 [B, L, 3, H, d] (the qkv Linear output as stored, no permute copies);
- * out: bf16 [B, L, H, d]; lse: fp32 [B, H, L].  d in {64, 128, 256}; L % 128 == 0.
+ * out: bf16 [B, L, H, d]; lse: fp32 [B, H, L].  d in {64, 128, 256}; any L >= 1 (ragged tails are masked).
  * drop_p: dropout on P (attention.py:57,69,76). */
 int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
                     uint64_t seed, void* stream);

@@ -36,9 +36,10 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 // stage a [64 rows][D] tile; rows are tokens tok0..tok0+63 of one head: src(row) = base + row*stride
-template <int D>
+// (rows >= nvalid are read from row nvalid-1: ragged sequence lengths never touch memory outside the tensor)
+template <int D, bool RAGGED>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t stride, char* tile, int wave,
-                                        int lane) {
+                                        int lane, int nvalid) {
   using C = Cfg<D>;
   constexpr int NI = C::TILE / 1024;  // instructions per tile (16 or 8)
 #pragma unroll
@@ -47,7 +48,10 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t 
     const int row = i * C::RPI + lane / C::CPR;
     const int cp = lane % C::CPR;
     const int c = cp ^ swz<D>(row);
-    glds16(base + (size_t)row * stride + c * 8, tile + i * 1024);
+    const int rsrc = (!RAGGED || row < nvalid) ? row : nvalid - 1;
+    // 32-bit per-lane byte offset on a wave-uniform base (saddr form): half the address registers of a 64-bit pointer
+    const uint32_t off = ((uint32_t)rsrc * (uint32_t)stride + (uint32_t)(c * 8)) * 2u;
+    glds16(reinterpret_cast<const char*>(base) + off, tile + i * 1024);
   }
 }
 
@@ -96,11 +100,12 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {
 
 // dropout on a 32x32 tile whose lane-local axis (registers) runs along KEYS: registers 4t..4t+3 are keys
 // kbase + 8t + 4h + {0..3} of query row qrow -> one hash per 4 registers.
-__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint64_t rowbase /* (bh*L+q)*L */,
-                                                  int kbase, int h, unsigned thr, float dscale) {
+// rowq = (bh*L+q)*(Lp/4) + h is the lane's group index at key 0 (Lp = L rounded up to 4); the per-tile part
+// (kbase/4 + 2t) is wave-uniform, so each hash index costs one 64-bit add.
+__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint64_t rowq, int kbase, unsigned thr) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint64_t idx = (rowbase + (uint64_t)(kbase + 8 * t + 4 * h)) >> 2;
+    const uint64_t idx = rowq + (uint64_t)((kbase >> 2) + 2 * t);
     const uint32_t hh = o2_hash64(seed, idx);
 #pragma unroll
     for (int e = 0; e < 4; ++e) p[4 * t + e] = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : 0.f;
@@ -110,7 +115,7 @@ __device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int D, bool DROP>
+template <int D, bool DROP, bool RAGGED>
 __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
                                                           unsigned thr, float dscale, uint64_t seed) {
@@ -125,7 +130,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
   const bf16_t* vbase = qbase + (size_t)2 * H * D;
-  const int qrow = q0 + (lane & 31);
+  const int qrow_raw = q0 + (lane & 31);
+  const bool q_ok = !RAGGED || qrow_raw < L;
+  const int qrow = q_ok ? qrow_raw : L - 1;   // ragged tail: compute on a valid row, never store it
 
   bf16x8 qf[C::NDS];
 #pragma unroll
@@ -138,11 +145,11 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  const uint64_t rowbase = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)L;
+  const uint64_t rowq = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)((L + 3) >> 2) + (uint64_t)hq;
 
-  const int nt = L / 64;
-  stage64<D>(kbase, tstride, smem, wave, lane);
-  stage64<D>(vbase, tstride, smem + C::TILE, wave, lane);
+  const int nt = (L + 63) / 64;
+  stage64<D, RAGGED>(kbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED>(vbase, tstride, smem + C::TILE, wave, lane, L);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -151,8 +158,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
     const char* sv = sk + C::TILE;
     if (t + 1 < nt) {
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane);
-      stage64<D>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane);
+      stage64<D, RAGGED>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
     }
     // S^T[kb] = K_kb . Q^T   (rows = keys in registers, column = query on the lane)
     f32x16 s[2];
@@ -163,6 +170,13 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
 #pragma unroll
       for (int ds = 0; ds < C::NDS; ++ds)
         s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s[kb]);
+    }
+    if (RAGGED && t == nt - 1 && (L & 63)) {   // keys past the end of a ragged sequence get no weight
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) s[kb][r] = -1e30f;
     }
     // online softmax over this lane's query row (its 32 keys + the partner half's 32)
     float mx = -1e30f;
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
     l_run = l_run * alpha + psum;
     if (DROP) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) drop_keys_in_regs(s[kb], seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
+      for (int kb = 0; kb < 2; ++kb) drop_keys_in_regs(s[kb], seed, rowq, t * 64 + kb * 32, thr);
     }
     // O^T[db] += V^T . P^T
 #pragma unroll
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
+  if (!q_ok) return;
   if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
   bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
 #pragma unroll
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =============================================================================================
 // backward, dQ: same geometry as the forward (query on the lane)
 // =============================================================================================
-template <int D, bool DROP>
+template <int D, bool DROP, bool RAGGED>
 __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                              const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse,
@@ -283,7 +298,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
   const bf16_t* vbase = qbase + (size_t)2 * H * D;
-  const int qrow = q0 + (lane & 31);
+  const int qrow_raw = q0 + (lane & 31);
+  const bool q_ok = !RAGGED || qrow_raw < L;
+  const int qrow = q_ok ? qrow_raw : L - 1;
   const float sc_log2 = scale * 1.4426950408889634f;
 
   bf16x8 qf[C::NDS], dof[C::NDS];
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
   const size_t sidx = ((size_t)(b * H + head)) * L + qrow;
   const float lse2 = lse[sidx] * 1.4426950408889634f;
   const float dlt = DROP ? delta[sidx] / dscale : delta[sidx];   // dscale folded into the final scale
-  const uint64_t rowbase = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)L;
+  const uint64_t rowq = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)((L + 3) >> 2) + (uint64_t)hq;
 
   f32x16 dq[C::NDB];
 #pragma unroll
@@ -304,9 +321,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-  const int nt = L / 64;
-  stage64<D>(kbase, tstride, smem, wave, lane);
-  stage64<D>(vbase, tstride, smem + C::TILE, wave, lane);
+  const int nt = (L + 63) / 64;
+  stage64<D, RAGGED>(kbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED>(vbase, tstride, smem + C::TILE, wave, lane, L);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -315,8 +332,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
     const char* sv = sk + C::TILE;
     if (t + 1 < nt) {
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane);
-      stage64<D>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane);
+      stage64<D, RAGGED>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -328,10 +345,12 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
         s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s);
         dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], dp);
       }
-      if (DROP) drop_keys_in_regs(dp, seed, rowbase, t * 64 + kb * 32, hq, thr, dscale);
+      if (DROP) drop_keys_in_regs(dp, seed, rowq, t * 64 + kb * 32, thr);
+      const bool tail = RAGGED && (t == nt - 1) && (L & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse2);
+        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse2);
+        if (tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) p = 0.f;   // key past the end
         s[r] = p * (dp[r] - dlt);  // dS^T
       }
 #pragma unroll
@@ -346,6 +365,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
     __syncthreads();
     cur ^= 1;
   }
+  if (!q_ok) return;
   bf16_t* drow = dqkv + ((size_t)b * L + qrow) * tstride + (size_t)head * D;
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
 // WHICH: 0 = dK and dV in one pass (d = 64: fits 2 waves/SIMD);  1 = dK only;  2 = dV only.
 // At d = 128 the fused form needs 236 VGPR + 160 AGPR (1 wave/SIMD, measured 576 TFLOP/s executed); split in two
 // passes (5 MFMA products instead of 4) each pass fits 2 waves/SIMD.
-template <int D, bool DROP, int WHICH>
+template <int D, bool DROP, int WHICH, bool RAGGED>
 __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
@@ -387,7 +407,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
   const bf16_t* kbase = qbase + (size_t)H * D;
   const bf16_t* vbase = qbase + (size_t)2 * H * D;
   const bf16_t* dobase = dout + (size_t)b * L * ostride + (size_t)head * D;
-  const int krow = k0 + (lane & 31);
+  const int krow_raw = k0 + (lane & 31);
+  const bool k_ok = !RAGGED || krow_raw < L;
+  const int krow = k_ok ? krow_raw : L - 1;
   const float sc_log2 = scale * 1.4426950408889634f;
   float* sstat = reinterpret_cast<float*>(smem + 4 * C::TILE);
 
@@ -408,18 +430,23 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 
   const size_t sbase = ((size_t)(b * H + head)) * L;
   const uint64_t bh = (uint64_t)(b * H + head);
-  const uint32_t lq = (uint32_t)(L >> 2);   // L % 128 == 0
-  const int nt = L / 64;
+  const uint32_t lq = (uint32_t)((L + 3) >> 2);   // mask rows are padded to a multiple of 4 keys
+  const uint32_t hoff = (uint32_t)((lane & 3) + 4 * hq) * lq + (uint32_t)(krow >> 2);
+  const int nt = (L + 63) / 64;
   auto stage_stats = [&](int t, int buf) {
     if (tid < 128) {
       const int which = tid >> 6, i = tid & 63;
-      const float v = which ? (DROP ? delta[sbase + t * 64 + i] / dscale : delta[sbase + t * 64 + i])
-                            : lse[sbase + t * 64 + i] * 1.4426950408889634f;
+      float v;
+      if (!RAGGED || t * 64 + i < L)
+        v = which ? (DROP ? delta[sbase + t * 64 + i] / dscale : delta[sbase + t * 64 + i])
+                  : lse[sbase + t * 64 + i] * 1.4426950408889634f;
+      else
+        v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
       sstat[(buf * 2 + which) * 64 + i] = v;
     }
   };
-  stage64<D>(qbase, tstride, smem, wave, lane);
-  stage64<D>(dobase, ostride, smem + C::TILE, wave, lane);
+  stage64<D, RAGGED>(qbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED>(dobase, ostride, smem + C::TILE, wave, lane, L);
   stage_stats(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -429,8 +456,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
     const char* sdo = sq + C::TILE;
     if (t + 1 < nt) {
       char* nq = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane);
-      stage64<D>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane);
+      stage64<D, RAGGED>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane, L - (t + 1) * 64);
       stage_stats(t + 1, cur ^ 1);
     }
     const float* s_lse = sstat + (cur * 2 + 0) * 64;
@@ -448,37 +475,38 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
       }
       // dropout: one hash covers 4 consecutive keys = the 4 lanes of a quad; each lane hashes 4 of the 16
       // query rows (rows r with (r&3) == lane&3) and the quad shares them by DPP broadcast.
+      const int kbyte = 8 * (krow & 3);
+      // hash index = (wave-uniform 64-bit part) + (per-lane 32-bit part hoff)
+      const uint64_t hrow0 = (bh * (uint64_t)L + (uint64_t)(t * 64 + qb * 32)) * (uint64_t)lq;
+      // per-row statistics: registers 4g..4g+3 are 4 consecutive query rows -> one 16-byte LDS read per group,
+      // fetched just in time (keeps 32 VGPRs out of the MFMA section's live set)
       uint32_t hmine[4] = {0u, 0u, 0u, 0u};
       if (DROP) {
-        const int l3 = lane & 3;
 #pragma unroll
-        for (int tq = 0; tq < 4; ++tq) {
-          const uint64_t rowi = bh * (uint64_t)L + (uint64_t)(t * 64 + qb * 32 + l3 + 8 * tq + 4 * hq);
-          hmine[tq] = o2_hash64(seed, rowi * (uint64_t)lq + (uint64_t)(krow >> 2));
-        }
-      }
-      const int kbyte = 8 * (krow & 3);
-      // per-row statistics: registers 4g..4g+3 are 4 consecutive query rows -> one 16-byte LDS read each
-      f32x4 lse4[4], dl4[4];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        lse4[g4] = *reinterpret_cast<const f32x4*>(s_lse + qb * 32 + 8 * g4 + 4 * hq);
-        if (DO_DK) dl4[g4] = *reinterpret_cast<const f32x4*>(s_dlt + qb * 32 + 8 * g4 + 4 * hq);
+        for (int g4 = 0; g4 < 4; ++g4)
+          hmine[g4] = o2_hash64(seed, hrow0 + (uint64_t)(8 * g4) * (uint64_t)lq + (uint64_t)hoff);
       }
       f32x16 pd;  // P after dropout (for dV)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse4[r >> 2][r & 3]);
-        float dpr = dp[r];
-        float pdr = p;
-        if (DROP) {
-          const uint32_t hh = quad_bcast(hmine[r >> 2], r & 3);
-          const bool keep = ((hh >> kbyte) & 0xffu) >= thr;
-          dpr = keep ? dpr : 0.f;     // dscale is applied once, on the final dK / dV tiles
-          pdr = keep ? p : 0.f;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(s_lse + qb * 32 + 8 * g4 + 4 * hq);
+        f32x4 dl4 = {0.f, 0.f, 0.f, 0.f};
+        if (DO_DK) dl4 = *reinterpret_cast<const f32x4*>(s_dlt + qb * 32 + 8 * g4 + 4 * hq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g4 + e;
+          float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse4[e]);
+          float dpr = dp[r];
+          float pdr = p;
+          if (DROP) {
+            const uint32_t hh = quad_bcast(hmine[g4], e);
+            const bool keep = ((hh >> kbyte) & 0xffu) >= thr;
+            dpr = keep ? dpr : 0.f;     // dscale is applied once, on the final dK / dV tiles
+            pdr = keep ? p : 0.f;
+          }
+          if (DO_DV) pd[r] = pdr;
+          if (DO_DK) s[r] = p * (dpr - dl4[e]);  // dS
         }
-        if (DO_DV) pd[r] = pdr;
-        if (DO_DK) s[r] = p * (dpr - dl4[r >> 2][r & 3]);  // dS
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -500,6 +528,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
     __syncthreads();
     cur ^= 1;
   }
+  if (!k_ok) return;
   bf16_t* dkrow = dqkv + ((size_t)b * L + krow) * tstride + (size_t)H * D + (size_t)head * D;
   bf16_t* dvrow = dkrow + (size_t)H * D;
 #pragma unroll
@@ -528,7 +557,6 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 static int attn_check(const void* a, const void* b, int B, int L, int H, int d, float p) {
   if (!a || !b || B <= 0 || L <= 0 || H <= 0) return O2_ERR_ARG;
   if (d != 64 && d != 128 && d != 256) return O2_ERR_UNSUPPORTED;
-  if (L % 128) return O2_ERR_ARG;
   if (p < 0.f || p >= 1.f) return O2_ERR_ARG;
   return O2_OK;
 }
@@ -541,11 +569,18 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   const float sc_log2 = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
-  dim3 grid(L / 128, H, B), block(256);
+  dim3 grid((L + 127) / 128, H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool ragged = (L % 128) != 0;
 #define O2_FWD(DV, DR)                                                                                              \
-  hipLaunchKernelGGL((attn_fwd_kernel<DV, DR>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H,   \
-                     sc_log2, thr, dscale, seed)
+  do {                                                                                                              \
+    if (ragged)                                                                                                     \
+      hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, true>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out,    \
+                         lse, L, H, sc_log2, thr, dscale, seed);                                                    \
+    else                                                                                                            \
+      hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, false>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out,   \
+                         lse, L, H, sc_log2, thr, dscale, seed);                                                    \
+  } while (0)
   if (d == 256) { if (thr) O2_FWD(256, true); else O2_FWD(256, false); }
   else if (d == 128) { if (thr) O2_FWD(128, true); else O2_FWD(128, false); }
   else { if (thr) O2_FWD(64, true); else O2_FWD(64, false); }
@@ -567,14 +602,25 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, s,
                      (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
   O2_CHECK_LAUNCH();
-  dim3 grid(L / 128, H, B), block(256);
+  dim3 grid((L + 127) / 128, H, B), block(256);
   const bf16_t* q_ = (const bf16_t*)qkv;
   const bf16_t* do_ = (const bf16_t*)dout;
   bf16_t* dq_ = (bf16_t*)dqkv;
-#define O2_DQ(DV, DR) \
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale, seed)
-#define O2_DKV(DV, DR, W) \
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale, seed)
+  const bool ragged = (L % 128) != 0;
+#define O2_DQ(DV, DR)                                                                                               \
+  do {                                                                                                              \
+    if (ragged) hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, true>), grid, block, 0, s, q_, do_, lse, delta, dq_, \
+                                   L, H, scale, thr, dscale, seed);                                                 \
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, false>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, \
+                            scale, thr, dscale, seed);                                                              \
+  } while (0)
+#define O2_DKV(DV, DR, W)                                                                                           \
+  do {                                                                                                              \
+    if (ragged) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W, true>), grid, block, 0, s, q_, do_, lse, delta,  \
+                                   dq_, L, H, scale, thr, dscale, seed);                                            \
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W, false>), grid, block, 0, s, q_, do_, lse, delta, dq_,   \
+                            L, H, scale, thr, dscale, seed);                                                        \
+  } while (0)
   if (d == 256) {
     if (thr) { O2_DQ(256, true); O2_DKV(256, true, 1); O2_DKV(256, true, 2); }
     else { O2_DQ(256, false); O2_DKV(256, false, 1); O2_DKV(256, false, 2); }

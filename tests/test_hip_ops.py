@@ -144,7 +144,8 @@ def _attn_ref(qkv, B, L, H, d, mask=None, sc=1.0):
     return (a @ v).transpose(1, 2).reshape(B, L, H * d)
 
 
-@pytest.mark.parametrize("d,H,L,B", [(64, 2, 128, 2), (128, 2, 256, 1), (64, 4, 512, 1), (128, 3, 384, 2), (256, 2, 128, 1), (256, 1, 256, 2)])
+@pytest.mark.parametrize("d,H,L,B", [(64, 2, 128, 2), (128, 2, 256, 1), (64, 4, 512, 1), (128, 3, 384, 2), (256, 2, 128, 1), (256, 1, 256, 2),
+                                       (128, 2, 200, 1), (64, 2, 578, 2), (128, 1, 70, 2), (256, 1, 161, 1)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attention_fwd_bwd(hip, d, H, L, B, p):
     g = torch.Generator().manual_seed(d + L)
@@ -153,8 +154,9 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
     seed = 99887766
     mask, sc = None, 1.0
     if p > 0:
-        m, sc = keep_mask(seed, B * H * L * L, p)
-        mask = torch.from_numpy(m).view(B, H, L, L)
+        Lp = (L + 3) // 4 * 4              # mask rows are padded to a multiple of 4 keys (csrc/attn.hip)
+        m, sc = keep_mask(seed, B * H * L * Lp, p)
+        mask = torch.from_numpy(m).view(B, H, L, Lp)[..., :L]
     ref = _attn_ref(qkv, B, L, H, d, mask, sc)
     ref.backward(do)
     qd = bf(qkv.detach()).cuda()
