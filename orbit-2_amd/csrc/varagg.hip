@@ -10,7 +10,8 @@
 // The two tables depend on the weights only (built per step by small fp32 GEMMs with autograd); this kernel
 // does the per-token work and never materialises the [B,V,L,D] tensor (1.16 GB/sample at interm_1b) nor runs
 // the M = B*L*V "kv" GEMM.  Exact algebra; only the rounding order differs from the reference.
-#include "common.h"
+#include <stdlib.h>
+#include "tiles32.h"
 #include "../../include/orbit2_hip.h"
 
 namespace {
@@ -184,6 +185,249 @@ __global__ __launch_bounds__(256) void varagg_kernel(const float* __restrict__ x
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward on the matrix cores (head dims 64 / 128 / 256, 5V <= 128).  Per head h and 32-token chunk:
+//   G[t,(v,c)]   = sum_{d in h} dz[t,d] * gtab[(v,c),d]                       (MFMA, contraction over the head dim)
+//   da[t,v]      = sum_c pt[t,v,c] * G[t,(v,c)] ;  ds = a * (da - sum_u a_u da_u)       (softmax backward, VALU)
+//   dstab[h,v,c] += sum_t ds[t,v] * pt[t,v,c]
+//   dgtab[(v,c),d] += sum_t (a[t,v] pt[t,v,c]) * dz[t,d]                     (MFMA, contraction over the tokens)
+// One workgroup owns (head, token range); its dgtab block lives in MFMA accumulators for the whole range and
+// is added to HBM once (fp32 atomics: 5V x DH floats per workgroup instead of 5V x D per 16 tokens).
+// dz is bf16 as stored; the fp32 operands (gtab, a*pt) enter as bf16 hi + bf16 lo pairs (two MFMAs, ~16 mantissa
+// bits; at head dim 256 gtab is hi only, LDS), accumulation is fp32.
+constexpr int VM_NV = 128;    // padded (v,c) extent
+constexpr int VM_GS = 132;    // fp32 row stride of the G image
+constexpr int VM_T = 32;      // tokens per chunk
+
+// stage a [32 rows][D] tile (same image as stage64's, half the rows); rows >= nvalid repeat row nvalid-1
+template <int D>
+__device__ __forceinline__ void stage32(const bf16_t* __restrict__ base, size_t stride, char* tile, int wave,
+                                        int lane, int nvalid) {
+  using C = Cfg<D>;
+  constexpr int NI = VM_T * C::RB / 1024;  // LDS-DMA instructions per tile: 4 / 8 / 16
+#pragma unroll
+  for (int t = 0; t < NI / 4; ++t) {
+    const int i = wave * (NI / 4) + t;
+    const int row = i * C::RPI + lane / C::CPR;
+    const int c = (lane % C::CPR) ^ swz<D>(row);
+    const int rsrc = row < nvalid ? row : nvalid - 1;
+    const uint32_t off = ((uint32_t)rsrc * (uint32_t)stride + (uint32_t)(c * 8)) * 2u;
+    glds16(reinterpret_cast<const char*>(base) + off, tile + i * 1024);
+  }
+}
+
+__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void varagg_bwd_mfma_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ gtab,
+                                                                 const float* __restrict__ attw,
+                                                                 const bf16_t* __restrict__ dz,
+                                                                 float* __restrict__ dstab, float* __restrict__ dgtab,
+                                                                 int B, int V, int h, int w, int H, int D,
+                                                                 int chunks_per_wg) {
+  using CZ = Cfg<DH>;
+  using CA = Cfg<VM_NV>;
+  constexpr bool GLO = DH <= 128;                             // gtab lo image
+  constexpr int GT_BYTES = VM_NV * CZ::RB;
+  constexpr int A2_BYTES = VM_T * CA::RB;
+  constexpr int NDBZ = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char vsm[];
+  char* zt = vsm;                                             // [32][DH] bf16 (LDS-DMA, swizzled)
+  char* gthi = zt + VM_T * CZ::RB;                            // [128][DH] bf16 (swizzled like a tile)
+  char* gtlo = gthi + GT_BYTES;
+  char* a2hi = gtlo + (GLO ? GT_BYTES : 0);                   // [32][128] bf16 (swizzled)
+  char* a2lo = a2hi + A2_BYTES;
+  float* gimg = reinterpret_cast<float*>(a2lo + A2_BYTES);    // [32][VM_GS] fp32
+  float* pt = gimg + VM_T * VM_GS;                            // [32][V][4]
+  float* aw = pt + VM_T * V * 4;                              // [32][V]
+  float* dsv = aw + VM_T * V;                                 // [32][V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;
+  const int hh = blockIdx.x;
+  const int Lw = w / 2, L = (h / 2) * Lw;
+  const int ntok = B * L;
+  const int nchunk = (ntok + VM_T - 1) / VM_T;
+  const int c0 = blockIdx.y * chunks_per_wg;
+  const int c1 = min(nchunk, c0 + chunks_per_wg);
+  if (c0 >= c1) return;
+  const int NV5 = 5 * V;
+  const int NB = (NV5 + 31) / 32;
+  const bool wave_on = wave < NB;                             // wave <-> 32-row block of (v,c)
+  const bf16_t* zbase = dz + (size_t)hh * DH;
+
+  // gtab block of this head -> bf16 hi/lo tiles (rows >= 5V are zero)
+  for (int e = tid; e < VM_NV * (DH / 8); e += 256) {
+    const int row = e / (DH / 8), c = e % (DH / 8);
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vh[j] = 0; vl[j] = 0; }
+    if (row < NV5) {
+      const float* src = gtab + (size_t)row * D + (size_t)hh * DH + c * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16_t hi, lo;
+        split_bf16(src[j], hi, lo);
+        vh[j] = (short)hi; vl[j] = (short)lo;
+      }
+    }
+    const int off = row * CZ::RB + ((c ^ swz<DH>(row)) << 4);
+    *reinterpret_cast<bf16x8*>(gthi + off) = vh;
+    if (GLO) *reinterpret_cast<bf16x8*>(gtlo + off) = vl;
+  }
+  // the a*pt images: columns >= 5V stay zero for the whole kernel
+  for (int e = tid; e < 2 * A2_BYTES / 16; e += 256) {
+    bf16x8 zz;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zz[j] = 0;
+    reinterpret_cast<bf16x8*>(a2hi)[e] = zz;
+  }
+
+  f32x16 acc[NDBZ];                                           // dgtab rows [32*wave, +32) x the head's DH columns
+#pragma unroll
+  for (int i = 0; i < NDBZ; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // dstab partial of this thread: (v,c) = tid % 128 (if < 5V), tokens [16*(tid/128), +16) of every chunk
+  const int se = tid & 127, shalf = tid >> 7;
+  const int sv = se / 5, sc = se - 5 * sv;
+  float sacc = 0.f;
+
+  for (int ch = c0; ch < c1; ++ch) {
+    const int tok0 = ch * VM_T;
+    stage32<DH>(zbase + (size_t)tok0 * D, (size_t)D, zt, wave, lane, ntok - tok0);
+    // ---- patches + attention weights of the chunk: thread -> (token, k); loops over variables ----------------
+    {
+      const int t = tid >> 3, k = tid & 7, c = k & 3;
+      const int tok = tok0 + t;
+      const bool ok = tok < ntok;
+      const int tk = ok ? tok : ntok - 1;
+      const int b = tk / L, l = tk - b * L;
+      const int pr = l / Lw, pc = l - pr * Lw;
+      const float* xp = x + ((size_t)b * V * h + (2 * pr + (c >> 1))) * w + 2 * pc + (c & 1);
+      const float* ap = attw + ((size_t)tk * H + hh) * V;
+      for (int v = k >> 2; v < V; v += 2) pt[(t * V + v) * 4 + c] = ok ? xp[(size_t)v * h * w] : 0.f;
+      for (int v = k; v < V; v += 8) aw[t * V + v] = ok ? ap[v] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // B1: z tile, pt, aw visible
+    // ---- G = dz . gtab^T : wave -> (v,c) block ------------------------------------------------------------------
+    if (wave_on) {
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < CZ::NDS; ++ds) {
+        const bf16x8 zf = row_frag<DH>(zt, lane & 31, ds, hq);
+        g = MFMA32(zf, row_frag<DH>(gthi, wave * 32 + (lane & 31), ds, hq), g);
+        if (GLO) g = MFMA32(zf, row_frag<DH>(gtlo, wave * 32 + (lane & 31), ds, hq), g);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = (r & 3) + 8 * (r >> 2) + 4 * hq;
+        gimg[t * VM_GS + wave * 32 + (lane & 31)] = g[r];
+      }
+    }
+    __syncthreads();                                   // B2: G visible
+    // ---- softmax backward; 8 threads per token ------------------------------------------------------------------
+    {
+      const int t = tid >> 3, sub = tid & 7;
+      float dav[4];
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = sub + 8 * k;
+        dav[k] = 0.f;
+        if (v < V) {
+          const float* gp = gimg + t * VM_GS + 5 * v;
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(pt + (t * V + v) * 4);
+          dav[k] = p4[0] * gp[0] + p4[1] * gp[1] + p4[2] * gp[2] + p4[3] * gp[3] + gp[4];
+          dot += aw[t * V + v] * dav[k];
+        }
+      }
+      dot += __shfl_xor(dot, 1);
+      dot += __shfl_xor(dot, 2);
+      dot += __shfl_xor(dot, 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = sub + 8 * k;
+        if (v < V) {
+          const float a = aw[t * V + v];
+          dsv[t * V + v] = a * (dav[k] - dot);
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(pt + (t * V + v) * 4);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const int col = 5 * v + c;
+            bf16_t hi, lo;
+            split_bf16(c < 4 ? a * p4[c] : a, hi, lo);
+            const int off = t * CA::RB + (((col >> 3) ^ swz<VM_NV>(t)) << 4) + (col & 7) * 2;
+            *reinterpret_cast<bf16_t*>(a2hi + off) = hi;
+            *reinterpret_cast<bf16_t*>(a2lo + off) = lo;
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // B3: ds and the a*pt images visible
+    // ---- dgtab += (a pt)^T . dz  (contraction over the chunk's tokens) ----------------------------------------------
+    if (wave_on) {
+#pragma unroll
+      for (int ks = 0; ks < VM_T / 16; ++ks) {
+        const bf16x8 ah = tr_frag<VM_NV>(a2hi, ks * 16, wave, lane);
+        const bf16x8 al = tr_frag<VM_NV>(a2lo, ks * 16, wave, lane);
+#pragma unroll
+        for (int db = 0; db < NDBZ; ++db) {
+          const bf16x8 zf = tr_frag<DH>(zt, ks * 16, db, lane);
+          acc[db] = MFMA32(ah, zf, acc[db]);
+          acc[db] = MFMA32(al, zf, acc[db]);
+        }
+      }
+    }
+    // ---- dstab partial ------------------------------------------------------------------------------------------
+    if (se < NV5) {
+#pragma unroll 4
+      for (int t = shalf * (VM_T / 2); t < (shalf + 1) * (VM_T / 2); ++t)
+        sacc += dsv[t * V + sv] * (sc < 4 ? pt[(t * V + sv) * 4 + sc] : 1.f);
+    }
+    __syncthreads();                                   // B4: chunk consumed; the images may be overwritten
+  }
+  if (se < NV5) atomicAdd(dstab + ((size_t)hh * V + sv) * 5 + sc, sacc);
+  if (wave_on) {
+#pragma unroll
+    for (int db = 0; db < NDBZ; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;
+        if (row < NV5) atomicAdd(dgtab + (size_t)row * D + (size_t)hh * DH + db * 32 + (lane & 31), acc[db][r]);
+      }
+  }
+}
+
+template <int DH>
+static void varagg_bwd_mfma_launch(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
+                                   float* dgtab, int B, int V, int h, int w, int H, int D, int ntok, hipStream_t s) {
+  const int nchunk = (ntok + VM_T - 1) / VM_T;
+  // ~3 workgroups per CU over (heads x token ranges); each range amortises one 5V x dh atomic flush
+  int splits = (768 + H - 1) / H;
+  if (splits > nchunk) splits = nchunk;
+  const int cpw = (nchunk + splits - 1) / splits;
+  splits = (nchunk + cpw - 1) / cpw;
+  const size_t shm = (size_t)VM_T * DH * 2 + (size_t)VM_NV * DH * 2 * (DH <= 128 ? 2 : 1) + 2 * (size_t)VM_T * VM_NV * 2 +
+                     sizeof(float) * (size_t)(VM_T * VM_GS + VM_T * V * 4 + 2 * VM_T * V);
+  static bool attr_set = false;   // one flag per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)varagg_bwd_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(varagg_bwd_mfma_kernel<DH>, dim3((unsigned)H, (unsigned)splits), dim3(256), shm, s, x, gtab, attw,
+                     (const bf16_t*)dz, dstab, dgtab, B, V, h, w, H, D, cpw);
+}
+
 }  // namespace
 
 static int va_check(int B, int V, int h, int w, int H, int D) {
@@ -212,6 +456,16 @@ extern "C" int orbit2_varagg_bwd(const float* x, const float* gtab, const float*
   int rc = va_check(B, V, h, w, H, D);
   if (rc) return rc;
   const int64_t ntok = (int64_t)B * (h / 2) * (w / 2);
+  const int dh = D / H;
+  static const bool force_scalar = getenv("ORBIT2_VARAGG_SCALAR") != nullptr;   // debugging aid: the fp32 VALU kernel
+  if (!force_scalar && (dh == 64 || dh == 128 || dh == 256) && 5 * V <= VM_NV && ntok < (1ll << 31) - 64) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dh == 64) varagg_bwd_mfma_launch<64>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, s);
+    else if (dh == 128) varagg_bwd_mfma_launch<128>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, s);
+    else varagg_bwd_mfma_launch<256>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, s);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
+  }
   const size_t shm = sizeof(float) * (size_t)(VA_T * V * 5 + 2 * VA_T * H * V);
   hipLaunchKernelGGL(varagg_kernel<true>, dim3((unsigned)((ntok + VA_T - 1) / VA_T)), dim3(256), shm,
                      (hipStream_t)stream, x, (const float*)nullptr, gtab, (bf16_t*)nullptr, (float*)attw,

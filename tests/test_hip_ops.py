@@ -209,7 +209,8 @@ def _tables(sd, heads, ids, D):
     return stab.contiguous(), gtab.contiguous()
 
 
-@pytest.mark.parametrize("D,heads,V,hw", [(64, 4, 5, (8, 16)), (256, 4, 23, (16, 32)), (384, 3, 7, (12, 20))])
+@pytest.mark.parametrize("D,heads,V,hw", [(64, 4, 5, (8, 16)), (256, 4, 23, (16, 32)), (384, 3, 7, (12, 20)),
+                                           (256, 2, 25, (32, 64)), (512, 2, 5, (8, 16))])
 def test_varagg_fold_matches_dense_oracle(hip, D, heads, V, hw):
     cfg = O.Config(["v%d" % i for i in range(V + 2)], hw, 1, D, 1, 1, heads)
     sd = O.init_state_dict(cfg, V, seed=1)
@@ -243,7 +244,9 @@ def test_varagg_fold_matches_dense_oracle(hip, D, heads, V, hw):
     for k in leaves:
         if leaves[k].grad is None:
             continue
-        assert nerr(leaves2[k].grad, leaves[k].grad) < 2e-3, k
+        # head dims 64/128/256 take the MFMA backward: fp32 operands enter as bf16 hi+lo pairs (fp32-grade result),
+        # except gtab at head dim 256 (hi only, LDS capacity) -> bf16-grade on the score-table path
+        assert nerr(leaves2[k].grad, leaves[k].grad) < (5e-3 if D // heads == 256 else 5e-5 if D // heads >= 64 else 2e-5), k
 
 
 # ---------------------------------------------------------------------------------------------
