@@ -52,6 +52,12 @@ typedef struct {
 } orbit2_gemm_args;
 int orbit2_gemm_bf16(const orbit2_gemm_args* args, void* stream);
 
+/* n (<= ORBIT2_GEMM_MAX_GROUP) independent problems of ONE operand form (same a_kc, b_kc) in one launch of the
+ * 128x128 kernel: the partially filled last round of each problem is filled with the next one's tiles.  Used for
+ * the four weight-gradient GEMMs of a Block (reference: autograd of attention.py:36,40 + mlp.py:50,54). */
+#define ORBIT2_GEMM_MAX_GROUP 8
+int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream);
+
 /* small fp32 GEMM (parameter-table algebra of the folded variable aggregation):
  * C[M,N] = alpha * op(A) * op(B) + beta*C, row-major fp32; ta/tb: 0 = as stored, 1 = transposed. */
 int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -109,15 +109,13 @@ timer: Optional[KernelTimer] = None
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None, dgelu_pre=None,
-         drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0, res_first=False,
-         beta=0.0, tile=0):
-    """out[M,N] = epilogue(A x B); see include/orbit2_hip.h:orbit2_gemm_bf16."""
+def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None,
+               dgelu_pre=None, drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0,
+               res_first=False, beta=0.0, tile=0):
     for t, nm in ((A, "A"), (B, "B")):
         _dev(t, BF, nm)
     if out.dtype not in (BF, F32) or not out.is_cuda:
         raise HipBackendError("gemm out must be a bf16/fp32 GPU tensor")
-    a = GemmArgs()
     a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
     a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, lda, ldb, ldc
     a.a_kc, a.b_kc = int(a_kc), int(b_kc)
@@ -133,15 +131,45 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act
     a.out_fp32 = int(out.dtype == F32)
     a.beta = float(beta)
     a.tile_hint = int(tile)
+    return 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0)
+
+
+def gemm(A, B, out, M, N, K, lda, ldb, ldc, **kw):
+    """out[M,N] = epilogue(A x B); see include/orbit2_hip.h:orbit2_gemm_bf16."""
+    a = GemmArgs()
+    flops, nbytes = _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, **kw)
     if timer is not None:
-        e0, e1 = timer.span("gemm_bf16", 2.0 * M * N * K,
-                            2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0))
+        e0, e1 = timer.span("gemm_bf16", flops, nbytes)
         e0.record()
         _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
         e1.record()
         return out
     _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
     return out
+
+
+GEMM_MAX_GROUP = 8
+
+
+def gemm_grouped(problems):
+    """problems: list of (A, B, out, M, N, K, lda, ldb, ldc, kwargs) sharing one operand form; one launch
+    (include/orbit2_hip.h:orbit2_gemm_bf16_grouped)."""
+    n = len(problems)
+    if not 0 < n <= GEMM_MAX_GROUP:
+        raise HipBackendError("gemm_grouped takes 1..%d problems" % GEMM_MAX_GROUP)
+    arr = (GemmArgs * n)()
+    flops = nbytes = 0.0
+    for i, (A, B, out, M, N, K, lda, ldb, ldc, kw) in enumerate(problems):
+        f, b = _gemm_fill(arr[i], A, B, out, M, N, K, lda, ldb, ldc, **kw)
+        flops += f
+        nbytes += b
+    if timer is not None:
+        e0, e1 = timer.span("gemm_bf16", flops, nbytes)
+        e0.record()
+        _chk(lib().orbit2_gemm_bf16_grouped(arr, n, _stream()), "orbit2_gemm_bf16_grouped")
+        e1.record()
+        return
+    _chk(lib().orbit2_gemm_bf16_grouped(arr, n, _stream()), "orbit2_gemm_bf16_grouped")
 
 
 def sgemm(A, B, out, M, N, K, lda, ldb, ldc, ta=False, tb=False, alpha=1.0, beta=0.0):

@@ -118,6 +118,36 @@ def _dw(dy2d, x2d, W, b, M, N, K):
     return gw, gb
 
 
+class _DwBatch:
+    """Weight-gradient GEMMs of one autograd node, deferred and issued as ONE grouped launch: the last, partially
+    filled round of workgroups of each problem is filled by the next problem's tiles (dW grids are small: the
+    proj dW of interm_1b is 576 tiles on 512 workgroup slots).  Bias gradients (column sums) are issued at once."""
+
+    def __init__(self):
+        self.problems, self.sinks, self.keep = [], [], []
+
+    def add(self, dy2d, x2d, W, b, M, N, K):
+        """queues dW[N,K] = dy^T . x; returns (index of the weight result, bias result)"""
+        sw = _GradSink(W)
+        self.problems.append((dy2d, x2d, sw.buf, N, K, M, N, K, K, dict(a_kc=False, b_kc=False, beta=sw.beta)))
+        self.sinks.append(sw)
+        self.keep.append((dy2d, x2d))
+        gb = None
+        if b is not None:
+            sb = _GradSink(b)
+            _hip.colsum(dy2d, M, N, N, sb.buf, beta=sb.beta)
+            gb = sb.done()
+        return len(self.sinks) - 1, gb
+
+    def flush(self):
+        """launches the group; returns the per-problem values backward must return for the weights"""
+        for i in range(0, len(self.problems), _hip.GEMM_MAX_GROUP):
+            _hip.gemm_grouped(self.problems[i:i + _hip.GEMM_MAX_GROUP])
+        out = [s.done() for s in self.sinks]
+        self.problems, self.sinks, self.keep = [], [], []
+        return out
+
+
 def _ln_bwd(dy, x, gamma_p, beta_p, mean, rstd, dres):
     sg, sb = _GradSink(gamma_p), _GradSink(beta_p)
     assert sg.beta == sb.beta
@@ -198,27 +228,30 @@ class BlockFn(torch.autograd.Function):
         dx2 = dx2.reshape(M, D)
         if dx2.dtype != BF or not dx2.is_contiguous():
             dx2 = dx2.contiguous().to(BF)
-        # ---- MLP branch
+        # ---- MLP branch   (the four dW GEMMs are queued and issued as one grouped launch at the end)
+        dws = _DwBatch()
         dym2 = _drop_bwd(dx2, M, D, p_mlp, s2, dp2, L)
-        gw2, gb2 = _dw(dym2, hm, w2, b2, M, D, hid)
+        i2, gb2 = dws.add(dym2, hm, w2, b2, M, D, hid)
         dpre = _dx(dym2, w2, M, D, hid, drop_p=p_mlp, seed=s1, dgelu_pre=pre)
         del hm, pre, dym2
-        gw1, gb1 = _dw(dpre, h2, w1, b1, M, hid, D)
+        i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D)
         dh2 = _dx(dpre, w1, M, hid, D)
         del dpre, h2
         dx1, gn2w, gn2b = _ln_bwd(dh2, x1, n2w, n2b, mean2, rstd2, dx2)
         del dh2, x1
         # ---- attention branch
         dym1 = _drop_bwd(dx1, M, D, p_proj, sp, dp1, L)
-        gwp, gbp = _dw(dym1, o2d, wp, bp, M, D, D)
+        ip, gbp = dws.add(dym1, o2d, wp, bp, M, D, D)
         do = _dx(dym1, wp, M, D, D)
         del dym1
         dqkv = _hip.attn_bwd(qkv, o2d, do, lse, B, L, H, d, p_attn, sa)
         del do, o2d, qkv
-        gwqkv, gbqkv = _dw(dqkv, h1, wqkv, bqkv, M, 3 * D, D)
+        iq, gbqkv = dws.add(dqkv, h1, wqkv, bqkv, M, 3 * D, D)
         dh1 = _dx(dqkv, wqkv, M, 3 * D, D)
         del dqkv, h1
         dx, gn1w, gn1b = _ln_bwd(dh1, x2d, n1w, n1b, mean1, rstd1, dx1)
+        gws = dws.flush()
+        gw2, gw1, gwp, gwqkv = gws[i2], gws[i1], gws[ip], gws[iq]
         return (dx.view(B, L, D), None, gn1w, gn1b, gwqkv, gbqkv, gwp, gbp, gn2w, gn2b, gw1, gb1, gw2, gb2)
 
 

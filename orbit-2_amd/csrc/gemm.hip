@@ -144,22 +144,25 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
   }
 }
 
+// XCD-aware remap (bijective for any grid size): blocks b, b+8, .. share an XCD -> give each XCD a
+// contiguous range of tile ids.
+__device__ __forceinline__ int xcd_tile_id() {
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+}
+
+// one 128x128 output tile (tile `id` of the problem; tiles are walked in groups of 8 tile-rows so neighbours
+// share panels)
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm128_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         int M, int N, int K, int lda, int ldb, int tiles_m,
-                                                         int tiles_n, Epi epi) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
+__device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
+                                             int K, int lda, int ldb, int tiles_m, int tiles_n, const Epi& epi,
+                                             int id, char* smem) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware remap (bijective for any grid size): blocks b, b+8, .. share an XCD -> give each XCD a
-  // contiguous range of tile ids, then walk tiles in groups of 8 tile-rows so neighbours share panels.
-  const int nwg = gridDim.x;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   constexpr int GROUP = 8;
   const int per_group = GROUP * tiles_n;
   const int grp = id / per_group;
@@ -218,6 +221,40 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const bf16_t* __restric
       epilogue4(epi, m, n, acc[i][j]);
     }
   }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         int M, int N, int K, int lda, int ldb, int tiles_m,
+                                                         int tiles_n, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
+  gemm128_tile<A_KC, B_KC>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+}
+
+// Grouped launch: up to O2_GEMM_MAX_GROUP independent problems of one operand form share a grid, so the tail
+// round of each (tiles mod 512 workgroup slots) is filled by the next problem's tiles.  Used for the four weight
+// gradients of a transformer block: 576 + 1728 + 2304 + 2304 tiles in 14 rounds instead of 2 + 4 + 5 + 5.
+struct GProb {
+  const bf16_t* A;
+  const bf16_t* B;
+  int M, N, K, lda, ldb, tiles_m, tiles_n, tile_end;
+  Epi epi;
+};
+struct GArgs {
+  int n;
+  GProb p[ORBIT2_GEMM_MAX_GROUP];
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm128_grouped_kernel(GArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int id = xcd_tile_id();
+  int pi = 0;
+  while (pi + 1 < g.n && id >= g.p[pi].tile_end) ++pi;
+  const int first = pi ? g.p[pi - 1].tile_end : 0;
+  const GProb& P = g.p[pi];
+  const Epi epi = P.epi;
+  gemm128_tile<A_KC, B_KC>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
 }
 
 // ==========================================================================================
@@ -441,14 +478,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 
 extern "C" int orbit2_abi_version(void) { return ORBIT2_ABI_VERSION; }
 
-extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
+static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (!a || !a->A || !a->B || !a->C) return O2_ERR_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return O2_ERR_ARG;
   if (a->K % BK || a->N % 8 || a->M % 8 || a->lda % 8 || a->ldb % 8 || a->ldc % 4) return O2_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
-  Epi e;
   e.bias = (const bf16_t*)a->bias;
   e.save_pre = (bf16_t*)a->save_pre;
   e.dgelu_pre = (const bf16_t*)a->dgelu_pre;
@@ -461,6 +497,41 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   e.thr = (unsigned)(a->drop_p * 256.0f + 0.5f);
   e.dscale = 256.0f / (256.0f - (float)e.thr);
   e.beta = a->beta;
+  return O2_OK;
+}
+
+extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream) {
+  if (!args || n <= 0 || n > ORBIT2_GEMM_MAX_GROUP) return O2_ERR_ARG;
+  if (n == 1) return orbit2_gemm_bf16(args, stream);
+  GArgs g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const orbit2_gemm_args* a = args + i;
+    if (a->a_kc != args[0].a_kc || a->b_kc != args[0].b_kc) return O2_ERR_ARG;   // one operand form per group
+    const int rc = gemm_make_epi(a, g.p[i].epi);
+    if (rc) return rc;
+    GProb& P = g.p[i];
+    P.A = (const bf16_t*)a->A; P.B = (const bf16_t*)a->B;
+    P.M = a->M; P.N = a->N; P.K = a->K; P.lda = a->lda; P.ldb = a->ldb;
+    P.tiles_m = (a->M + BM - 1) / BM; P.tiles_n = (a->N + BN - 1) / BN;
+    total += P.tiles_m * P.tiles_n;
+    P.tile_end = total;
+  }
+  dim3 grid(total), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm128_grouped_kernel<true, true>), grid, block, 0, s, g);
+  else if (args[0].a_kc) hipLaunchKernelGGL((gemm128_grouped_kernel<true, false>), grid, block, 0, s, g);
+  else if (args[0].b_kc) hipLaunchKernelGGL((gemm128_grouped_kernel<false, true>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm128_grouped_kernel<false, false>), grid, block, 0, s, g);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
+  Epi e;
+  const int rc_epi = gemm_make_epi(a, e);
+  if (rc_epi) return rc_epi;
   hipStream_t s = (hipStream_t)stream;
   const bf16_t* A = (const bf16_t*)a->A;
   const bf16_t* B = (const bf16_t*)a->B;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void varagg_kernel(const float* __restrict__ x
 // One workgroup owns (head, token range); its dgtab block lives in MFMA accumulators for the whole range and
 // is added to HBM once (fp32 atomics: 5V x DH floats per workgroup instead of 5V x D per 16 tokens).
 // dz is bf16 as stored; the fp32 operands (gtab, a*pt) enter as bf16 hi + bf16 lo pairs (two MFMAs, ~16 mantissa
-// bits; at head dim 256 gtab is hi only, LDS), accumulation is fp32.
+// bits), accumulation is fp32.  The gtab fragments are loop-invariant and live in registers.
 constexpr int VM_NV = 128;    // padded (v,c) extent
 constexpr int VM_GS = 132;    // fp32 row stride of the G image
 constexpr int VM_T = 32;      // tokens per chunk
@@ -223,7 +223,7 @@ __device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256, 1) void varagg_bwd_mfma_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, (DH == 256 ? 1 : 2)) void varagg_bwd_mfma_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ gtab,
                                                                  const float* __restrict__ attw,
                                                                  const bf16_t* __restrict__ dz,
@@ -232,15 +232,11 @@ __global__ __launch_bounds__(256, 1) void varagg_bwd_mfma_kernel(const float* __
                                                                  int chunks_per_wg) {
   using CZ = Cfg<DH>;
   using CA = Cfg<VM_NV>;
-  constexpr bool GLO = DH <= 128;                             // gtab lo image
-  constexpr int GT_BYTES = VM_NV * CZ::RB;
   constexpr int A2_BYTES = VM_T * CA::RB;
   constexpr int NDBZ = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char vsm[];
   char* zt = vsm;                                             // [32][DH] bf16 (LDS-DMA, swizzled)
-  char* gthi = zt + VM_T * CZ::RB;                            // [128][DH] bf16 (swizzled like a tile)
-  char* gtlo = gthi + GT_BYTES;
-  char* a2hi = gtlo + (GLO ? GT_BYTES : 0);                   // [32][128] bf16 (swizzled)
+  char* a2hi = zt + VM_T * CZ::RB;                            // [32][128] bf16 (swizzled)
   char* a2lo = a2hi + A2_BYTES;
   float* gimg = reinterpret_cast<float*>(a2lo + A2_BYTES);    // [32][VM_GS] fp32
   float* pt = gimg + VM_T * VM_GS;                            // [32][V][4]
@@ -261,24 +257,26 @@ __global__ __launch_bounds__(256, 1) void varagg_bwd_mfma_kernel(const float* __
   const bool wave_on = wave < NB;                             // wave <-> 32-row block of (v,c)
   const bf16_t* zbase = dz + (size_t)hh * DH;
 
-  // gtab block of this head -> bf16 hi/lo tiles (rows >= 5V are zero)
-  for (int e = tid; e < VM_NV * (DH / 8); e += 256) {
-    const int row = e / (DH / 8), c = e % (DH / 8);
-    bf16x8 vh, vl;
+  // gtab rows [32*wave, +32) of this head as MFMA operand fragments, bf16 hi + lo, held in registers for the whole
+  // kernel (rows >= 5V are zero): lane (i, hq) owns row 32*wave + i, columns 16*ds + 8*hq + {0..7}
+  bf16x8 gfh[CZ::NDS], gfl[CZ::NDS];
+  {
+    const int row = wave * 32 + (lane & 31);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { vh[j] = 0; vl[j] = 0; }
-    if (row < NV5) {
-      const float* src = gtab + (size_t)row * D + (size_t)hh * DH + c * 8;
+    for (int ds = 0; ds < CZ::NDS; ++ds) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bf16_t hi, lo;
-        split_bf16(src[j], hi, lo);
-        vh[j] = (short)hi; vl[j] = (short)lo;
+      for (int j = 0; j < 8; ++j) { gfh[ds][j] = 0; gfl[ds][j] = 0; }
+      if (row < NV5) {
+        const float* src = gtab + (size_t)row * D + (size_t)hh * DH + ds * 16 + 8 * hq;
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16_t hi, lo;
+          split_bf16(j < 4 ? lo4[j] : hi4[j - 4], hi, lo);
+          gfh[ds][j] = (short)hi; gfl[ds][j] = (short)lo;
+        }
       }
     }
-    const int off = row * CZ::RB + ((c ^ swz<DH>(row)) << 4);
-    *reinterpret_cast<bf16x8*>(gthi + off) = vh;
-    if (GLO) *reinterpret_cast<bf16x8*>(gtlo + off) = vl;
   }
   // the a*pt images: columns >= 5V stay zero for the whole kernel
   for (int e = tid; e < 2 * A2_BYTES / 16; e += 256) {
@@ -324,8 +322,8 @@ __global__ __launch_bounds__(256, 1) void varagg_bwd_mfma_kernel(const float* __
 #pragma unroll
       for (int ds = 0; ds < CZ::NDS; ++ds) {
         const bf16x8 zf = row_frag<DH>(zt, lane & 31, ds, hq);
-        g = MFMA32(zf, row_frag<DH>(gthi, wave * 32 + (lane & 31), ds, hq), g);
-        if (GLO) g = MFMA32(zf, row_frag<DH>(gtlo, wave * 32 + (lane & 31), ds, hq), g);
+        g = MFMA32(zf, gfh[ds], g);
+        g = MFMA32(zf, gfl[ds], g);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -416,7 +414,7 @@ static void varagg_bwd_mfma_launch(const float* x, const float* gtab, const floa
   if (splits > nchunk) splits = nchunk;
   const int cpw = (nchunk + splits - 1) / splits;
   splits = (nchunk + cpw - 1) / cpw;
-  const size_t shm = (size_t)VM_T * DH * 2 + (size_t)VM_NV * DH * 2 * (DH <= 128 ? 2 : 1) + 2 * (size_t)VM_T * VM_NV * 2 +
+  const size_t shm = (size_t)VM_T * DH * 2 + 2 * (size_t)VM_T * VM_NV * 2 +
                      sizeof(float) * (size_t)(VM_T * VM_GS + VM_T * V * 4 + 2 * VM_T * V);
   static bool attr_set = false;   // one flag per instantiation
   if (!attr_set) {

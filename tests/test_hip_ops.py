@@ -63,6 +63,32 @@ def test_gemm_forms(hip, M, N, K, form, tile):
     assert nerr(outb, ref) < 6e-3  # one bf16 rounding of the result (2^-8 relative)
 
 
+@pytest.mark.parametrize("form", ["tn", "nt"])
+def test_gemm_grouped_matches_single_launches(hip, form):
+    """one grouped launch == the same problems launched one by one (same kernel, same tile walk: bit-identical),
+    with ragged tile counts and a beta-accumulating member"""
+    g = torch.Generator().manual_seed(77)
+    a_kc, b_kc = form[0] == "n", form[1] == "t"
+    shapes = [(200, 136, 128), (384, 520, 192), (128, 128, 64), (72, 1032, 256)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A = bf(torch.randn((M, K) if a_kc else (K, M), generator=g)).cuda()
+        B = bf(torch.randn((N, K) if b_kc else (K, N), generator=g)).cuda()
+        beta = 1.0 if i == 1 else 0.0
+        c0 = bf(torch.randn(M, N, generator=g)).cuda()
+        single = c0.clone()
+        hip.gemm(A, B, single, M, N, K, A.shape[1], B.shape[1], N, a_kc=a_kc, b_kc=b_kc, beta=beta, tile=128)
+        out = c0.clone()
+        probs.append((A, B, out, M, N, K, A.shape[1], B.shape[1], N, dict(a_kc=a_kc, b_kc=b_kc, beta=beta)))
+        refs.append(single)
+        ref32 = (A.float().cpu() if a_kc else A.float().cpu().t()) @ (B.float().cpu().t() if b_kc else B.float().cpu())
+        assert nerr(single, ref32 + beta * c0.float().cpu()) < 8e-3
+    hip.gemm_grouped(probs)
+    torch.cuda.synchronize()
+    for pr, ref in zip(probs, refs):
+        assert torch.equal(pr[2], ref)
+
+
 def test_gemm_epilogue_full(hip):
     M, N, K, L = 256, 192, 128, 64
     g = torch.Generator().manual_seed(5)
@@ -244,9 +270,8 @@ def test_varagg_fold_matches_dense_oracle(hip, D, heads, V, hw):
     for k in leaves:
         if leaves[k].grad is None:
             continue
-        # head dims 64/128/256 take the MFMA backward: fp32 operands enter as bf16 hi+lo pairs (fp32-grade result),
-        # except gtab at head dim 256 (hi only, LDS capacity) -> bf16-grade on the score-table path
-        assert nerr(leaves2[k].grad, leaves[k].grad) < (5e-3 if D // heads == 256 else 5e-5 if D // heads >= 64 else 2e-5), k
+        # head dims 64/128/256 take the MFMA backward: fp32 operands enter as bf16 hi+lo pairs (fp32-grade result)
+        assert nerr(leaves2[k].grad, leaves[k].grad) < 5e-5, k
 
 
 # ---------------------------------------------------------------------------------------------
