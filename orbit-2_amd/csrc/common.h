@@ -64,6 +64,31 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// GELU / GELU' for the bf16 GEMM epilogues: Phi(x) through erfc's rational-exponential form (Abramowitz & Stegun
+// 7.1.26, |abs err| <= 1.5e-7, evaluated on |x| so the negative tail has no cancellation): one v_rcp + one v_exp
+// + 7 FMAs instead of ocml erff (~40 instructions).  The results are rounded to bf16 (quantum >= 2^-9 relative),
+// the fp32 image path (conv GELU) keeps the erff forms above.
+__device__ __forceinline__ float o2_half_erfc_abs(float x, float& e) {   // 0.5*erfc(|x|/sqrt2), e = exp(-x^2/2)
+  const float u = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
+  return 0.5f * p * t * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float e;
+  const float y = o2_half_erfc_abs(x, e);
+  return x * (x > 0.f ? 1.0f - y : y);
+}
+__device__ __forceinline__ float dgelu_fast(float x) {
+  float e;
+  const float y = o2_half_erfc_abs(x, e);
+  return (x > 0.f ? 1.0f - y : y) + x * 0.3989422804014327f * e;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

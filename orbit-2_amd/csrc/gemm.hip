@@ -91,7 +91,7 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
   }
   if (e.act == 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+    for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
   }
   float r4[4] = {0.f, 0.f, 0.f, 0.f};
   if (e.residual) {
@@ -112,8 +112,8 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
   }
   if (e.dgelu_pre) {
     const u32x2 pr = *reinterpret_cast<const u32x2*>(e.dgelu_pre + off);
-    v[0] *= dgelu_f(bf2f((bf16_t)(pr[0] & 0xffff))); v[1] *= dgelu_f(bf2f((bf16_t)(pr[0] >> 16)));
-    v[2] *= dgelu_f(bf2f((bf16_t)(pr[1] & 0xffff))); v[3] *= dgelu_f(bf2f((bf16_t)(pr[1] >> 16)));
+    v[0] *= dgelu_fast(bf2f((bf16_t)(pr[0] & 0xffff))); v[1] *= dgelu_fast(bf2f((bf16_t)(pr[0] >> 16)));
+    v[2] *= dgelu_fast(bf2f((bf16_t)(pr[1] & 0xffff))); v[3] *= dgelu_fast(bf2f((bf16_t)(pr[1] >> 16)));
   }
   if (e.rowscale) {
     const float s = e.rowscale[m / e.rows_per_scale];
@@ -142,6 +142,91 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
     u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
     *reinterpret_cast<u32x2*>(c) = o;
   }
+}
+
+// ---- wide epilogue (bf16 output): one lane owns 8 consecutive n of one row m -------------------------------------
+// The 16x16x32 accumulators give each lane 4 consecutive n per fragment; v_permlane16_swap between the fragments j
+// and j+1 regroups them so that a lane holds 8 consecutive n (16 bytes of bf16): every epilogue load and store is a
+// dwordx4 instead of two dwordx2 (the store tail is issue-bound), and loads are issued in batches ahead of the
+// stores so no load queues behind a store (vmcnt retires in order).
+__device__ __forceinline__ void unpack8(const u32x4& r, float* f) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = bf2f((bf16_t)(r[k] & 0xffff)); f[2 * k + 1] = bf2f((bf16_t)(r[k] >> 16)); }
+}
+__device__ __forceinline__ u32x4 pack8(const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+  return o;
+}
+struct Pre8 { u32x4 res, pre, old; };
+
+__device__ __forceinline__ void epi8_load(const Epi& e, int m, int n, Pre8& q) {
+  if (m >= e.M || n >= e.N) return;
+  const size_t off = (size_t)m * e.ldc + n;
+  if (e.residual) {
+    const int rm = e.res_mod > 0 ? (m % e.res_mod) : m;
+    q.res = *reinterpret_cast<const u32x4*>(e.residual + (size_t)rm * e.ldr + n);
+  }
+  if (e.dgelu_pre) q.pre = *reinterpret_cast<const u32x4*>(e.dgelu_pre + off);
+  if (e.beta != 0.f) q.old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(e.C) + off);
+}
+
+__device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v, const float* bias8, const Pre8& q) {
+  if (m >= e.M || n >= e.N) return;
+  const size_t off = (size_t)m * e.ldc + n;
+  if (e.bias) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+  }
+  if (e.save_pre) {
+    const u32x4 o = pack8(v);
+    *reinterpret_cast<u32x4*>(e.save_pre + off) = o;
+    unpack8(o, v);   // the backward recomputes GELU'(pre) from the ROUNDED value: round here too
+  }
+  if (e.act == 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+  }
+  float r8[8];
+  if (e.residual) {
+    unpack8(q.res, r8);
+    if (e.res_first) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r8[k];
+    }
+  }
+  if (e.thr) {
+    const uint64_t idx = ((uint64_t)m * (uint64_t)e.N + (uint64_t)n) >> 2;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const uint32_t h = o2_hash64(e.seed, idx + hlf);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * hlf + j] = (((h >> (8 * j)) & 0xffu) >= e.thr) ? v[4 * hlf + j] * e.dscale : 0.f;
+    }
+  }
+  if (e.dgelu_pre) {
+    float p8[8];
+    unpack8(q.pre, p8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast(p8[k]);
+  }
+  if (e.rowscale) {
+    const float s = e.rowscale[m / e.rows_per_scale];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= s;
+  }
+  if (e.residual && !e.res_first) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += r8[k];
+  }
+  if (e.beta != 0.f) {
+    float o8[8];
+    unpack8(q.old, o8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += e.beta * o8[k];
+  }
+  *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(e.C) + off) = pack8(v);
 }
 
 // XCD-aware remap (bijective for any grid size): blocks b, b+8, .. share an XCD -> give each XCD a
@@ -404,13 +489,55 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   if (wave < 4) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
 
+  if (epi.out_fp32) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-      epilogue4(epi, m, n, acc[i][j]);
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        epilogue4(epi, m, n, acc[i][j]);
+      }
+    }
+    return;
+  }
+  // wide path: after the swap of fragments (2jp, 2jp+1), the lane in 16-lane row r4 owns
+  // n = nw + 32*jp + 16*(r4&1) + 8*(r4>>1) + {0..7} of row m
+  const int r4 = lane >> 4;
+  const int nw = n0 + wn * 64 + 16 * (r4 & 1) + 8 * (r4 >> 1);
+  float bias8[2][8];
+  if (epi.bias) {
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int n = nw + 32 * jp;
+      u32x4 b = {0u, 0u, 0u, 0u};
+      if (n < epi.N) b = *reinterpret_cast<const u32x4*>(epi.bias + n);
+      unpack8(b, bias8[jp]);
+    }
+  }
+#pragma unroll
+  for (int ib = 0; ib < 8; ib += 2) {
+    Pre8 q[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+        epi8_load(epi, m0 + wm * 128 + (ib + ii) * 16 + (lane & 15), nw + 32 * jp, q[ii][jp]);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int m = m0 + wm * 128 + (ib + ii) * 16 + (lane & 15);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ib + ii][2 * jp][c]),
+                                                           __float_as_uint(acc[ib + ii][2 * jp + 1][c]), false, false);
+          v[c] = __uint_as_float(sw[0]);
+          v[4 + c] = __uint_as_float(sw[1]);
+        }
+        epi8_finish(epi, m, nw + 32 * jp, v, bias8[jp], q[ii][jp]);
+      }
     }
   }
 }

@@ -1,6 +1,7 @@
 // Hardware self-test: checks, with exact small-integer data, every lane<->element map the kernels rely on
 // (MI355X guide section 3 / T10).  bit 0: 16x16x32 MFMA maps, bit 1: 32x32x16 MFMA maps, bit 2: LDS-DMA is
-// lane-linear, bit 3: ds_read_b64_tr_b16 block transpose, bit 4: accumulator-as-operand k order.
+// lane-linear, bit 3: ds_read_b64_tr_b16 block transpose, bit 4: accumulator-as-operand k order, bit 5:
+// v_permlane16_swap row map (wide GEMM epilogue), bit 6: fast GELU/GELU' within 1.5e-6 of the erff forms.
 #include "common.h"
 #include "../../include/orbit2_hip.h"
 
@@ -81,6 +82,18 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* result, const bf16_t*
         ref += A2(row, k) * xk;
       }
       if ((int)y[r] != ref) fail |= 16;
+    }
+  }
+  {  // ---- v_permlane16_swap: r0 = [a row0, b row0, a row2, b row2], r1 = [a row1, b row1, a row3, b row3]
+    const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)l, 100u + (unsigned)l, false, false);
+    const int r4 = l >> 4, i = l & 15;
+    const unsigned e0 = ((r4 & 1) ? 100u : 0u) + 16u * (unsigned)(r4 & 2) + (unsigned)i;
+    if (sw[0] != e0 || sw[1] != e0 + 16u) fail |= 32;
+  }
+  {  // ---- fast GELU / GELU' (bf16 GEMM epilogues) against the erff forms on [-9, 9]
+    for (int k = 0; k < 64; ++k) {
+      const float x = -9.0f + (float)(l * 64 + k) * (18.0f / 4095.0f);
+      if (fabsf(gelu_fast(x) - gelu_f(x)) > 1.5e-6f || fabsf(dgelu_fast(x) - dgelu_f(x)) > 1.5e-6f) fail |= 64;
     }
   }
   if (fail) atomicOr(result, fail);

@@ -89,7 +89,8 @@ def test_gemm_grouped_matches_single_launches(hip, form):
         assert torch.equal(pr[2], ref)
 
 
-def test_gemm_epilogue_full(hip):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_epilogue_full(hip, tile):
     M, N, K, L = 256, 192, 128, 64
     g = torch.Generator().manual_seed(5)
     A, W = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.2)
@@ -104,21 +105,28 @@ def test_gemm_epilogue_full(hip):
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     sp = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     hip.gemm(bf(A).cuda(), bf(W).cuda(), out, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_pre=sp, drop_p=p,
-             seed=seed, rowscale=rs.cuda(), rows_per_scale=M // 4, residual=bf(res).cuda(), ldr=N, res_mod=L)
+             seed=seed, rowscale=rs.cuda(), rows_per_scale=M // 4, residual=bf(res).cuda(), ldr=N, res_mod=L, tile=tile)
     assert nerr(sp, pre) < 6e-3
     assert nerr(out, ref) < 8e-3
     # res_first: dropout applied after the residual add (pos-embed path), beta accumulate, fp32 out
     ref2 = (A @ W.t() + bias + res.repeat(M // L, 1)) * mask * sc
     out2 = torch.ones(M, N, dtype=torch.float32, device="cuda")
     hip.gemm(bf(A).cuda(), bf(W).cuda(), out2, M, N, K, K, K, N, bias=bf(bias).cuda(), drop_p=p, seed=seed,
-             residual=bf(res).cuda(), ldr=N, res_mod=L, res_first=True, beta=0.5)
+             residual=bf(res).cuda(), ldr=N, res_mod=L, res_first=True, beta=0.5, tile=tile)
     assert nerr(out2, ref2 + 0.5) < 1e-4
+    out2b = torch.ones(M, N, dtype=torch.bfloat16, device="cuda")     # same through the bf16-output path
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), out2b, M, N, K, K, K, N, bias=bf(bias).cuda(), drop_p=p, seed=seed,
+             residual=bf(res).cuda(), ldr=N, res_mod=L, res_first=True, beta=0.5, tile=tile)
+    assert nerr(out2b, ref2 + 0.5) < 6e-3
     # dgelu epilogue: out = (A x W) * mask * gelu'(pre)
     dg = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    hip.gemm(bf(A).cuda(), bf(W).cuda(), dg, M, N, K, K, K, N, dgelu_pre=sp, drop_p=p, seed=seed)
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), dg, M, N, K, K, K, N, dgelu_pre=sp, drop_p=p, seed=seed, tile=tile)
     prq = sp.float().cpu().requires_grad_()
     F.gelu(prq).sum().backward()
     assert nerr(dg, (A @ W.t()) * mask * sc * prq.grad) < 1e-4
+    dgb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), dgb, M, N, K, K, K, N, dgelu_pre=sp, drop_p=p, seed=seed, tile=tile)
+    assert nerr(dgb, (A @ W.t()) * mask * sc * prq.grad) < 6e-3
 
 
 def test_dropout_statistics(hip):
