@@ -44,6 +44,36 @@ def pmc(path, out, unit_kb=("FETCH_SIZE", "WRITE_SIZE")):
                 f.write("    %-24s avg %16.1f  n=%d%s\n" % (c, avg, len(v), extra))
 
 
+def traffic(fetch_csv, write_csv, out):
+    """FETCH_SIZE / WRITE_SIZE passes -> per-launch HBM-side bytes per kernel family (JSON read by bench.py)."""
+    import json
+    fam = {"gemm": ("gemm256_kernel", "gemm128_kernel", "gemm128_grouped_kernel"), "attn_fwd": ("attn_fwd_kernel",),
+           "attn_bwd_dq": ("attn_bwd_dq_kernel",), "attn_bwd_dkv": ("attn_bwd_dkv_kernel",)}
+    acc = {k: {"FETCH_SIZE": [], "WRITE_SIZE": []} for k in fam}
+    for path in (fetch_csv, write_csv):
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            for f, names in fam.items():
+                if any(k.startswith(n) for n in names) and r["Counter_Name"] in acc[f]:
+                    acc[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for f, d in acc.items():
+        if not d["FETCH_SIZE"]:
+            continue
+        fb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 2 * 1024     # gfx950: x2, unit KB
+        wb = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"])) * 1024
+        res[f] = {"launches": len(d["FETCH_SIZE"]), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                  "hbm_bytes_per_launch": fb + wb}
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1; FETCH_SIZE "
+                    "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B), counter unit KB; FETCH_SIZE "
+                    "is L2-miss traffic (Infinity-Cache hits included)")
+    res["_config"] = {"model": "interm_1b", "batch": 4, "grid": "128x256"}
+    json.dump(res, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    mode, src, dst = sys.argv[1:4]
-    (stats if mode == "stats" else pmc)(src, dst)
+    mode = sys.argv[1]
+    if mode == "traffic":
+        traffic(*sys.argv[2:5])
+    else:
+        (stats if mode == "stats" else pmc)(sys.argv[2], sys.argv[3])
