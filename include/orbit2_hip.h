@@ -30,14 +30,15 @@ int orbit2_abi_version(void);
  * input-gradient (a_kc=1,b_kc=0) and weight-gradient (a_kc=b_kc=0) forms.
  * Epilogue order: +bias -> save_pre -> GELU -> [+residual if res_first] -> dropout ->
  *   *gelu'(dgelu_pre) -> *rowscale[m / rows_per_scale] -> [+residual] -> C = beta*C + v.
- * Requirements: K % 64 == 0, N % 8 == 0, M % 8 == 0, lda/ldb/ldc % 8 == 0, 16-byte aligned bases. */
+ * Requirements: K % 64 == 0, N % 8 == 0, M % 8 == 0 unless a_kc (any M then), lda/ldb/ldc % 8 == 0, 16-byte aligned
+ * bases. */
 typedef struct {
   const void* A; const void* B; void* C;
   int M, N, K;
   int lda, ldb, ldc;
   int a_kc, b_kc;
   const void* bias;        /* bf16 [N] or NULL */
-  int act;                 /* 0 none, 1 GELU(erf)  (nn.GELU default, mlp.py:64) */
+  int act;                 /* 0 none, 1 GELU(erf)  (nn.GELU default, mlp.py:64), 2 ReLU (VGG16 convs of LPIPS) */
   void* save_pre;          /* bf16 [M][ldc] pre-activation copy, or NULL */
   const void* dgelu_pre;   /* bf16 [M][ldc]: multiply by GELU'(pre), or NULL */
   float drop_p;            /* nn.Dropout on the output element (attention.py:82, mlp.py:65,68) */
@@ -141,6 +142,37 @@ int orbit2_loss_fwd(const float* pred, const float* target, int Ht, int Wt, cons
 /* dpred = gscale[0] * d(aggregate)/dpred */
 int orbit2_loss_bwd(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, const float* chan_w,
                     const float* gscale, float* dpred, int B, int C, int H, int W, int kind, void* stream);
+
+/* ---- perceptual loss = L1 + 0.5 * mean_b LPIPS-VGG16 (metrics/functional.py:17-33, metrics.py:119-187) ------
+ * Feature maps are NHWC bf16, so each 3x3 VGG convolution is im2col + orbit2_gemm_bf16 (bias, act = 2) forward and
+ * orbit2_gemm_bf16 + col2im backward (input gradient only: LPIPS weights are frozen, metrics.py:127-128).
+ * Tap order of a 3x3 window: t = ky*3 + kx, offsets (ky-1, kx-1), zero padding.  C % 8 == 0. */
+/* col[p][t][c] = x[p + off_t][c];  x: [N][H][W][C], col: [N*H*W][9*C] */
+int orbit2_im2col3x3(const void* x, void* col, int N, int H, int W, int C, void* stream);
+/* g[p][c] = sum_t dcol[p - off_t][t][c]; with act != NULL: out = (g + tapg) * (act > 0)  (ReLU backward of the layer
+ * that produced act, plus the LPIPS tap gradient at that layer; tapg may be NULL) */
+int orbit2_col2im3x3(const void* dcol, const void* act, const void* tapg, void* out, int N, int H, int W, int C,
+                     void* stream);
+/* 2x2 / stride 2 max-pool (torchvision VGG16 features 4, 9, 16, 23); backward routes to the first maximum of the
+ * window (ATen's index rule) and fuses the ReLU mask of x and the tap gradient like col2im */
+int orbit2_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int orbit2_maxpool2_bwd(const void* g, const void* x, const void* tapg, void* dz, int N, int H, int W, int C,
+                        void* stream);
+/* first convolution 3 -> 64 (+ReLU) straight from the NCHW fp32 image with the LPIPS ScalingLayer fused;
+ * w1: fp32 [(t*3 + ci)][64], b1: fp32 [64]; out: [N][H][W][64] bf16 */
+int orbit2_lpips_conv1_fwd(const float* img, const float* w1, const float* b1, void* out, int N, int H, int W,
+                           void* stream);
+/* dimg (NCHW fp32) = conv1 input gradient / scale + l1_coef * sign(pred - target)   (the L1 term of the loss) */
+int orbit2_lpips_conv1_bwd(const void* dz, const float* w1, const float* pred, const float* target, float l1_coef,
+                           float* dimg, int N, int H, int W, void* stream);
+/* LPIPS head of one tap.  feats: [2B][HW][C] bf16, images 0..B-1 = prediction, B..2B-1 = target; lin: fp32 [C].
+ * fwd: val[b] += mean_px sum_c lin_c (f0_c/(|f0|+1e-10) - f1_c/(|f1|+1e-10))^2.   C in {64,128,256,512}.
+ * bwd: gout[b][px][c] = coef * d(sum_c ...)/d f0_c * (f0_c > 0)  -- the gradient w.r.t. the tap's PRE-ReLU output
+ * (bf16; a pixel whose prediction features are all zero gets 0 where autograd of sqrt at 0 would produce NaN) */
+int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, void* stream);
+int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, int B, int HW, int C, void* stream);
+/* out[0] += mean |a - b|   (F.l1_loss, metrics/functional.py:30) */
+int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, void* stream);
 
 /* ---- optimizer (utils/loaders.py:398-399 AdamW; ShardedGradScaler :732-742) ------------------ */
 /* flat fused AdamW over n elements: fp32 master p/m/v, gradient g (bf16 or fp32) multiplied by

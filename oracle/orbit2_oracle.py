@@ -9,7 +9,8 @@ baseline -- never as something the HIP product path falls back to.
 Pinned by: tests/golden/*.npz, produced by tests/golden/make_golden.py from the reference's own
 modules imported in the build container (tests/test_oracle_golden.py asserts agreement <=2e-5).
 Parts that stay "parity unpinned" (third-party code absent from /root/reference):
-train-mode dropout / DropPath RNG streams (timm 0.9.2, ATen bernoulli), LPIPS weights.
+train-mode dropout / DropPath RNG streams (timm 0.9.2, ATen bernoulli), and the LPIPS network of the
+`perceptual` loss (lpips package + weights absent; restated from the published algorithm, see lpips_vgg).
 
 Written functionally over a flat {name: tensor} state dict (the reference's checkpoint key
 names) so that it shares no structure with the product's nn.Module code.  Every function cites
@@ -338,6 +339,70 @@ def image_gradient(pred, target, var_names=None, var_weights=None):
         e1 = e1 * cw
         e2 = e2 * cw
     return e1.mean() + 0.1 * e2.mean()
+
+
+# --------------------------------------------------------------------------------------
+# perceptual loss = L1 + 0.5 * mean_b LPIPS-VGG16          (metrics/functional.py:17-33, metrics.py:119-187)
+# LPIPS lives in the third-party `lpips` package (unpinned in the reference's pyproject, weights not in the
+# tree) -> PARITY UNPINNED.  Restated from the published algorithm (Zhang et al. 2018, lpips 0.1.x, net='vgg',
+# version 0.1, spatial=False, eval mode => the lin layers' Dropout is inactive):
+#   ScalingLayer (x - shift) / scale ; torchvision VGG16 `features` taps after relu1_2, relu2_2, relu3_3,
+#   relu4_3, relu5_3 ; per tap: unit-normalise over channels (x / (||x||_2 + 1e-10)), squared difference,
+#   1x1 conv with the learned non-negative `lin` weights (no bias), spatial mean ; sum over the 5 taps.
+# --------------------------------------------------------------------------------------
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
+VGG16_TAPS = (1, 3, 6, 9, 12)            # conv indices (0-based) whose ReLU output is an LPIPS tap
+LPIPS_SHIFT = (-0.030, -0.088, -0.188)
+LPIPS_SCALE = (0.458, 0.448, 0.450)
+
+
+def init_lpips_weights(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """random stand-in weights (He-normal convs, small positive lins): `conv{i}.weight [Co,Ci,3,3]`,
+    `conv{i}.bias`, `lin{k}.weight [C]` -- the synthetic-throughput configuration of SURVEY 8(d).5"""
+    g = torch.Generator().manual_seed(seed)
+    sd, cin, i = {}, 3, 0
+    for c in VGG16_CFG:
+        if c == "M":
+            continue
+        sd["conv%d.weight" % i] = torch.randn(c, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+        sd["conv%d.bias" % i] = torch.randn(c, generator=g) * 0.05
+        cin = c
+        i += 1
+    for k, ci in enumerate(VGG16_TAPS):
+        ch = sd["conv%d.weight" % ci].shape[0]
+        sd["lin%d.weight" % k] = torch.rand(ch, generator=g) * (2.0 / ch)
+    return sd
+
+
+def lpips_vgg(x0: torch.Tensor, x1: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """[B,3,H,W] x2 -> [B] distances"""
+    shift = torch.tensor(LPIPS_SHIFT, dtype=x0.dtype).view(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE, dtype=x0.dtype).view(1, 3, 1, 1)
+
+    def feats(x):
+        h, out, i = (x - shift) / scale, [], 0
+        for c in VGG16_CFG:
+            if c == "M":
+                h = F.max_pool2d(h, 2, 2)
+                continue
+            h = F.relu(F.conv2d(h, sd["conv%d.weight" % i], sd["conv%d.bias" % i], padding=1))
+            if i in VGG16_TAPS:
+                out.append(h)
+            i += 1
+        return out
+
+    val = 0.0
+    for k, (f0, f1) in enumerate(zip(feats(x0), feats(x1))):
+        n0 = f0 / (f0.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+        n1 = f1 / (f1.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+        d = ((n0 - n1) ** 2 * sd["lin%d.weight" % k].view(1, -1, 1, 1)).sum(1)
+        val = val + d.mean((1, 2))
+    return val
+
+
+def perceptual(pred, target, lpips_sd):
+    """F.l1_loss(pred, target) + 0.5 * mean(LPIPS(pred, target))     (metrics/functional.py:30)"""
+    return (pred - target).abs().mean() + 0.5 * lpips_vgg(pred, target, lpips_sd).mean()
 
 
 LOSSES = {"mse": mse, "bayesian_tv": bayesian_tv}

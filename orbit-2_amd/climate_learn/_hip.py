@@ -414,3 +414,67 @@ def transpose_bf16(src, dst):
     R, Cc = src.shape
     _chk(lib().orbit2_transpose_bf16(_p(src), _p(dst), R, Cc, _stream()), "orbit2_transpose_bf16")
     return dst
+
+
+# ---- perceptual loss building blocks (csrc/lpips.hip) ----------------------------------------------------------
+def im2col3x3(x, N, H, W, Cc):
+    _dev(x, BF, "x")
+    col = torch.empty(N * H * W, 9 * Cc, dtype=BF, device=x.device)
+    _chk(lib().orbit2_im2col3x3(_p(x), _p(col), N, H, W, Cc, _stream()), "orbit2_im2col3x3")
+    return col
+
+
+def col2im3x3(dcol, N, H, W, Cc, act=None, tapg=None):
+    _dev(dcol, BF, "dcol")
+    out = torch.empty(N * H * W, Cc, dtype=BF, device=dcol.device)
+    _chk(lib().orbit2_col2im3x3(_p(dcol), _p(act), _p(tapg), _p(out), N, H, W, Cc, _stream()), "orbit2_col2im3x3")
+    return out
+
+
+def maxpool2_fwd(x, N, H, W, Cc):
+    _dev(x, BF, "x")
+    y = torch.empty(N * (H // 2) * (W // 2), Cc, dtype=BF, device=x.device)
+    _chk(lib().orbit2_maxpool2_fwd(_p(x), _p(y), N, H, W, Cc, _stream()), "orbit2_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(g, x, N, H, W, Cc, tapg=None):
+    _dev(g, BF, "g"); _dev(x, BF, "x")
+    dz = torch.empty(N * H * W, Cc, dtype=BF, device=g.device)
+    _chk(lib().orbit2_maxpool2_bwd(_p(g), _p(x), _p(tapg), _p(dz), N, H, W, Cc, _stream()), "orbit2_maxpool2_bwd")
+    return dz
+
+
+def lpips_conv1_fwd(img, w1, b1):
+    _dev(img, F32, "img"); _dev(w1, F32, "w1"); _dev(b1, F32, "b1")
+    N, _, H, W = img.shape
+    out = torch.empty(N * H * W, 64, dtype=BF, device=img.device)
+    _chk(lib().orbit2_lpips_conv1_fwd(_p(img), _p(w1), _p(b1), _p(out), N, H, W, _stream()), "orbit2_lpips_conv1_fwd")
+    return out
+
+
+def lpips_conv1_bwd(dz, w1, pred, target, l1_coef):
+    _dev(dz, BF, "dz"); _dev(pred, F32, "pred"); _dev(target, F32, "target")
+    N, _, H, W = pred.shape
+    dimg = torch.empty_like(pred)
+    _chk(lib().orbit2_lpips_conv1_bwd(_p(dz), _p(w1), _p(pred), _p(target), C.c_float(l1_coef), _p(dimg), N, H, W,
+                                      _stream()), "orbit2_lpips_conv1_bwd")
+    return dimg
+
+
+def lpips_tap_fwd(feats, lin, val, B, HW, Cc):
+    _dev(feats, BF, "feats"); _dev(lin, F32, "lin"); _dev(val, F32, "val")
+    _chk(lib().orbit2_lpips_tap_fwd(_p(feats), _p(lin), _p(val), B, HW, Cc, _stream()), "orbit2_lpips_tap_fwd")
+
+
+def lpips_tap_bwd(feats, lin, coef, B, HW, Cc):
+    _dev(feats, BF, "feats"); _dev(lin, F32, "lin")
+    g = torch.empty(B * HW, Cc, dtype=BF, device=feats.device)
+    _chk(lib().orbit2_lpips_tap_bwd(_p(feats), _p(lin), _p(g), C.c_float(coef), B, HW, Cc, _stream()),
+         "orbit2_lpips_tap_bwd")
+    return g
+
+
+def l1_mean(a, b, out):
+    _dev(a, F32, "a"); _dev(b, F32, "b"); _dev(out, F32, "out")
+    _chk(lib().orbit2_l1_mean(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "orbit2_l1_mean")

@@ -1,4 +1,4 @@
-"""Callable loss objects (reference: metrics/metrics.py).  Training-path losses only: mse, bayesian_tv and the
+"""Callable loss objects (reference: metrics/metrics.py).  Training-path losses only: mse, bayesian_tv, perceptual and the
 *intended* lat_mse (the reference's LatWeightedMSE passes its arguments positionally into
 the wrong slots and rejects the var_names/var_weights kwargs training_step always passes; here it computes
 mse(pred, target, var_names, var_weights, aggregate_only, lat_weights[:H_pred]))."""
@@ -59,14 +59,41 @@ class LatWeightedMSE(LatitudeWeightedMetric):
         return mse(pred, target, var_names, var_weights, self.aggregate_only, self.lat_weights)
 
 
+@register("perceptual")
+class PERCEPTUAL(Metric):
+    """L1 + 0.5 * mean LPIPS-VGG16 (reference: metrics.py:119-187, functional.py:17-33).  Same constructor as the
+    reference (device, model, aggregate_only, metainfo).  The reference's __call__ takes (pred, target) only, while
+    training_step always passes var_names= / var_weights=: they are accepted and ignored here.
+    LPIPS weights: a state dict file named by $ORBIT2_LPIPS_WEIGHTS (lpips / torchvision key names), otherwise
+    seeded random weights (synthetic-throughput configuration; lpips' pretrained file is not in the reference tree)."""
+
+    def __init__(self, device, model, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None):
+        import os
+        import warnings
+        from .lpips_hip import LPIPSVGG16
+        super().__init__(aggregate_only, metainfo)
+        self.model = model
+        path = os.environ.get("ORBIT2_LPIPS_WEIGHTS")
+        state = None
+        if path:
+            state = torch.load(path, map_location="cpu")
+        else:
+            warnings.warn("perceptual loss: no $ORBIT2_LPIPS_WEIGHTS file, using seeded random LPIPS-VGG16 weights")
+        self.loss_fn = LPIPSVGG16(device, state)
+
+    def __call__(self, pred, target, var_names: Optional[List[str]] = None,
+                 var_weights: Optional[Dict[str, float]] = None):
+        return self.loss_fn.perceptual(pred, target)
+
+
 def _not_on_path(name):
     class _M(Metric):
         def __call__(self, *a, **k):
             raise NotImplementedError(
-                "%s is an evaluation / perceptual metric outside the training hot path of this build" % name)
+                "%s is an evaluation metric outside the training hot path of this build" % name)
     _M.__name__ = name.upper()
     return register(name)(_M)
 
 
-for _n in ("rmse", "pearson", "mean_bias", "mae", "lat_rmse", "lat_acc", "acc", "perceptual"):
+for _n in ("rmse", "pearson", "mean_bias", "mae", "lat_rmse", "lat_acc", "acc"):
     _not_on_path(_n)

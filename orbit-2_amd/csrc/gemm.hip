@@ -92,6 +92,9 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
   if (e.act == 1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+  } else if (e.act == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
   }
   float r4[4] = {0.f, 0.f, 0.f, 0.f};
   if (e.residual) {
@@ -187,6 +190,9 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
   if (e.act == 1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+  } else if (e.act == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
   }
   float r8[8];
   if (e.residual) {
@@ -608,7 +614,9 @@ extern "C" int orbit2_abi_version(void) { return ORBIT2_ABI_VERSION; }
 static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (!a || !a->A || !a->B || !a->C) return O2_ERR_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return O2_ERR_ARG;
-  if (a->K % BK || a->N % 8 || a->M % 8 || a->lda % 8 || a->ldb % 8 || a->ldc % 4) return O2_ERR_ARG;
+  // rows of a K-contiguous operand are clamped at staging and masked at the store, so M is free there; an operand
+  // stored K-strided is fetched in 8-element pieces along its M / N axis; stores are 8 (bf16) / 4 (fp32) n wide
+  if (a->K % BK || a->N % 8 || (!a->a_kc && a->M % 8) || a->lda % 8 || a->ldb % 8 || a->ldc % 4) return O2_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;

@@ -63,6 +63,22 @@ def test_gemm_forms(hip, M, N, K, form, tile):
     assert nerr(outb, ref) < 6e-3  # one bf16 rounding of the result (2^-8 relative)
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M", [12, 100, 301])
+def test_gemm_any_row_count_when_a_is_k_contiguous(hip, M, tile):
+    """M need not be a multiple of 8 when A is K-contiguous (rows are clamped at staging, masked at the store)"""
+    N, K = 136, 128
+    g = torch.Generator().manual_seed(M)
+    A, B = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g))
+    bias = rt(torch.randn(N, generator=g))
+    guard = torch.full((M + 8, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(B).cuda(), guard, M, N, K, K, K, N, bias=bf(bias).cuda(), act=2, tile=tile)
+    assert nerr(guard[:M], torch.relu(A @ B.t() + bias)) < 6e-3
+    assert torch.all(guard[M:] == 7.0)                      # nothing written past row M-1
+    with pytest.raises(Exception):                          # still required for the K-strided A form
+        hip.gemm(bf(A.t().contiguous()).cuda(), bf(B).cuda(), guard, M, N, K, M + (-M) % 8, K, N, a_kc=False)
+
+
 @pytest.mark.parametrize("form", ["tn", "nt"])
 def test_gemm_grouped_matches_single_launches(hip, form):
     """one grouped launch == the same problems launched one by one (same kernel, same tile walk: bit-identical),
