@@ -409,11 +409,13 @@ LOSSES = {"mse": mse, "bayesian_tv": bayesian_tv}
 
 
 def training_loss(sd, cfg, x, y, in_variables, out_variables, loss_name="bayesian_tv", var_weights=None,
-                  lat=None):
+                  lat=None, lpips_sd=None):
     """training_step (:281-306): forward, clip, crop, loss (aggregate)."""
     pred = forward(sd, cfg, x, in_variables, out_variables)
     yhat = clip_replace_constant(y, pred, out_variables)
     tgt = crop_target(y, yhat)
+    if loss_name == "perceptual":
+        return perceptual(yhat, tgt, lpips_sd)
     if loss_name == "lat_mse":
         return mse(yhat, tgt, out_variables, var_weights or {}, True, lat_weights(lat, yhat.shape[2]))
     return LOSSES[loss_name](yhat, tgt, out_variables, var_weights or {}, True)

@@ -108,6 +108,10 @@ class LPIPSVGG16:
             raise ValueError("this LPIPS build needs H and W to be multiples of 16 (four 2x2 max-pools)")
 
     def perceptual(self, pred, target):
+        if target.shape[2] > pred.shape[2] or target.shape[3] > pred.shape[3]:
+            # the caller hands over the uncropped target (trainer.training_step); the reference crops it to the
+            # prediction before every loss (examples/intermediate_downscaling.py:295-296)
+            target = target[:, :, : pred.shape[2], : pred.shape[3]]
         self._check(pred, target)
         return _PerceptualFn.apply(pred, target, self)
 

@@ -145,6 +145,35 @@ def test_train_mode_dropout_and_recompute_match():
     assert abs(l_eval - grads[0][0]) > 1e-6
 
 
+def test_daymet_like_three_outputs_perceptual_loss():
+    """SURVEY 8(d) config 5, reduced: V = 7 inputs (4 constants + 3 outputs), C = 3, perceptual loss (seeded stand-in
+    LPIPS weights on both sides); loss and gradients through the whole model against the CPU oracle"""
+    from climate_learn.testing import build_pair, nerr
+    from climate_learn.metrics.lpips_hip import LPIPSVGG16
+    from climate_learn.trainer import training_step
+    outs = ("total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max")
+    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=1, heads=2, grid=(16, 32), B=2, seed=3,
+                                                            out_vars=outs)
+    lp = {k: (v.to(torch.bfloat16).float() if "lin" not in k else v) for k, v in O.init_lpips_weights(9).items()}
+    net = LPIPSVGG16("cuda", lp)
+
+    class _Loss:
+        def __call__(self, pred, target, var_names=None, var_weights=None):
+            return net.perceptual(pred, target)
+
+    dev = torch.device("cuda:0")
+    model = model.to(dev).eval()
+    loss = training_step((x, y, in_vars, out_vars), 0, model, dev, {"total_precipitation_24hr": 1.0}, _Loss())
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "perceptual", lpips_sd=lp)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 1e-2
+    for name, p in (("head.0.weight", model.head[0].weight), ("blocks.0.mlp.fc1.weight", model.blocks[0].mlp.fc1.weight),
+                    ("blocks.0.attn.qkv.weight", model.blocks[0].attn.qkv.weight), ("conv_out.weight", model.conv_out.weight)):
+        assert nerr(p.grad, sdo[name].grad) < 6e-2, name
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
