@@ -51,11 +51,7 @@ def init_par_groups(world_rank, data_par_size, tensor_par_size, seq_par_size, fs
 def load_checkpoint(model, path, rank):
     if rank == 0:
         print("model resume from checkpoint", path, flush=True)
-    ck = torch.load(path, map_location="cpu")
-    sd = ck["model_state_dict"]
-    interpolate_pos_embed(model, sd, new_size=model.img_size)
-    model.load_state_dict(sd)
-    return ck
+    return cl.utils.load_checkpoint(model, path)
 
 
 def main():
@@ -111,6 +107,10 @@ def main():
             ck = None
             if tr.get("checkpoint") and os.path.exists(str(tr["checkpoint"])):
                 ck = load_checkpoint(model, tr["checkpoint"], world_rank)
+            elif tr.get("pretrain"):       # shape-tolerant partial load (reference :70-80, :116-153)
+                if world_rank == 0:
+                    print("load pretrained model", tr["pretrain"], flush=True)
+                cl.utils.load_pretrained_weights(model, str(tr["pretrain"]), verbose=world_rank == 0)
             print("enter NO SHARD only,", flush=True)
             eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
                                      sync_module_states=True)

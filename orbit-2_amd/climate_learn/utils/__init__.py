@@ -1,4 +1,5 @@
 from .fused_attn import FusedAttn
+from .checkpoint import load_checkpoint, load_pretrained_weights
 from .loaders import (
     load_model_module,
     load_forecasting_module,

@@ -106,3 +106,38 @@ def test_checkpoint_pos_embed_interpolation_matches_oracle():
     same = {"pos_embed": pe.clone()}
     interpolate_pos_embed(SimpleNamespace(patch_size=2), same, new_size=(8, 16))
     assert torch.equal(same["pos_embed"], pe)
+
+
+def test_shape_tolerant_pretrain_load(tmp_path):
+    """reference examples/intermediate_downscaling.py:116-153: unknown keys dropped, mismatched shapes dropped except
+    pos_embed (bicubic resample to the model grid), the rest loaded non-strictly"""
+    from climate_learn.models.hub import Res_Slim_ViT
+    from climate_learn.utils import load_pretrained_weights, load_checkpoint
+    from oracle import orbit2_oracle as O
+    dv = CONST + ["total_precipitation_24hr"]
+    torch.manual_seed(0)
+    pre = Res_Slim_ViT(dv, (8, 16), 5, 1, 1, patch_size=2, embed_dim=128, depth=1, decoder_depth=1, num_heads=2)
+    sd = {k: v.clone() + 0.01 for k, v in pre.state_dict().items()}
+    sd["extra.not_in_model"] = torch.zeros(3)
+    path = os.path.join(tmp_path, "pre.ckpt")
+    torch.save({"epoch": 3, "model_state_dict": sd}, path)
+    # fine-tune model: another grid (pos_embed 32 -> 128 tokens) and 3 output channels (head / conv shapes differ)
+    dv3 = dv + ["2m_temperature_min", "2m_temperature_max"]
+    torch.manual_seed(1)
+    ft = Res_Slim_ViT(dv3, (16, 32), 7, 3, 1, patch_size=2, embed_dim=128, depth=1, decoder_depth=1, num_heads=2)
+    before = {k: v.clone() for k, v in ft.state_dict().items()}
+    loaded, no_key, bad = load_pretrained_weights(ft, path)
+    after = ft.state_dict()
+    assert no_key == ["extra.not_in_model"]
+    assert "pos_embed" in loaded and "pos_embed" not in bad
+    assert torch.allclose(after["pos_embed"], O.pos_embed_for_grid(sd["pos_embed"], 2, (16, 32)), atol=1e-6)
+    assert "blocks.0.attn.qkv.weight" in loaded and torch.equal(after["blocks.0.attn.qkv.weight"], sd["blocks.0.attn.qkv.weight"])
+    assert len(bad) > 0 and all(sd[k].shape != before[k].shape for k in bad)
+    for k in bad:                                              # untouched: still the fine-tune model's own init
+        assert torch.equal(after[k], before[k])
+    with pytest.raises(SystemExit):
+        load_pretrained_weights(ft, os.path.join(tmp_path, "missing.ckpt"))
+    # strict resume of the same architecture goes through load_checkpoint (pos_embed resample included)
+    torch.save({"epoch": 3, "model_state_dict": {k: v for k, v in sd.items() if k != "extra.not_in_model"}}, path)
+    ck = load_checkpoint(pre, path)
+    assert ck["epoch"] == 3 and torch.equal(pre.state_dict()["head.0.weight"], sd["head.0.weight"])
