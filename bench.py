@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="interm_1b")
     ap.add_argument("--grid", default="128x256")
-    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (SURVEY 8d config 3 sweeps 1..8; 8 amortises AdamW best)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--recompute", action="store_true", help="replay each Block in backward (activation ckpt)")

@@ -1,4 +1,5 @@
 set -e
+# usage (on the GPU box): bash tools/profile_round.sh   -- three rocprofv3 passes of the default bench configuration
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
@@ -8,8 +9,8 @@ echo fetch-done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof -o r01_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1
 echo write-done
 cd $R
-python tools/summarize_prof.py stats gpurun_out/prof/r01_kernel_stats.csv gpurun_out/r01_interm1b_b4_kernel_stats.txt
-python tools/summarize_prof.py pmc gpurun_out/prof/r01_fetch_counter_collection.csv gpurun_out/r01_interm1b_b4_pmc_traffic.txt
-python tools/summarize_prof.py pmc gpurun_out/prof/r01_write_counter_collection.csv gpurun_out/r01_interm1b_b4_pmc_traffic.txt
+python tools/summarize_prof.py stats gpurun_out/prof/r01_kernel_stats.csv gpurun_out/r01_interm1b_b8_kernel_stats.txt
+python tools/summarize_prof.py pmc gpurun_out/prof/r01_fetch_counter_collection.csv gpurun_out/r01_interm1b_b8_pmc_traffic.txt
+python tools/summarize_prof.py pmc gpurun_out/prof/r01_write_counter_collection.csv gpurun_out/r01_interm1b_b8_pmc_traffic.txt
 python tools/summarize_prof.py traffic gpurun_out/prof/r01_fetch_counter_collection.csv gpurun_out/prof/r01_write_counter_collection.csv gpurun_out/r01_traffic.json
 ls gpurun_out/prof
