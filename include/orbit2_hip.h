@@ -143,6 +143,11 @@ int orbit2_loss_fwd(const float* pred, const float* target, int Ht, int Wt, cons
 int orbit2_loss_bwd(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, const float* chan_w,
                     const float* gscale, float* dpred, int B, int C, int H, int W, int kind, void* stream);
 
+/* evaluation metrics (metrics/functional.py:236-324 rmse / pearson / mean_bias): out[b][c][6] (double) =
+ * {sum p, sum t, sum p^2, sum t^2, sum p*t, sum w_lat (p-t)^2} over the H*W pixels (target: top-left crop) */
+int orbit2_eval_moments(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, double* out, int B,
+                        int C, int H, int W, void* stream);
+
 /* ---- perceptual loss = L1 + 0.5 * mean_b LPIPS-VGG16 (metrics/functional.py:17-33, metrics.py:119-187) ------
  * Feature maps are NHWC bf16, so each 3x3 VGG convolution is im2col + orbit2_gemm_bf16 (bias, act = 2) forward and
  * orbit2_gemm_bf16 + col2im backward (input gradient only: LPIPS weights are frozen, metrics.py:127-128).

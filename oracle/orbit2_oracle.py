@@ -405,6 +405,37 @@ def perceptual(pred, target, lpips_sd):
     return (pred - target).abs().mean() + 0.5 * lpips_vgg(pred, target, lpips_sd).mean()
 
 
+# --------------------------------------------------------------------------------------
+# evaluation metrics (metrics/functional.py:236-324) -- pinned by tests/golden/eval_metrics.npz
+# --------------------------------------------------------------------------------------
+def rmse(pred, target, aggregate_only=False, lat_w=None):
+    """:236-255: sqrt of the per-(b,c) spatial mean of the (latitude-weighted) squared error, mean over b then c"""
+    err = (pred - target).square()
+    if lat_w is not None:
+        err = err * lat_w
+    return _reduce_vec(err.mean([2, 3]).sqrt().mean(0), aggregate_only)
+
+
+def pearson(pred, target, aggregate_only=False):
+    """:294-308: cosine similarity of the mean-removed [C, B*H*W] fields"""
+    C = pred.shape[1]
+    p = pred.transpose(0, 1).reshape(C, -1)
+    t = target.transpose(0, 1).reshape(C, -1)
+    p = p - p.mean(1, keepdim=True)
+    t = t - t.mean(1, keepdim=True)
+    return _reduce_vec(F.cosine_similarity(p, t), aggregate_only)
+
+
+def mean_bias(pred, target, aggregate_only=False):
+    """:311-324: mean(target) - mean(pred) per channel"""
+    return _reduce_vec(target.mean((0, 2, 3)) - pred.mean((0, 2, 3)), aggregate_only)
+
+
+def _reduce_vec(per_channel, aggregate_only):
+    agg = per_channel.mean()
+    return agg if aggregate_only else torch.cat((per_channel, agg.unsqueeze(0)))
+
+
 LOSSES = {"mse": mse, "bayesian_tv": bayesian_tv}
 
 

@@ -478,3 +478,13 @@ def lpips_tap_bwd(feats, lin, coef, B, HW, Cc):
 def l1_mean(a, b, out):
     _dev(a, F32, "a"); _dev(b, F32, "b"); _dev(out, F32, "out")
     _chk(lib().orbit2_l1_mean(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "orbit2_l1_mean")
+
+
+def eval_moments(pred, target, lat_w=None):
+    """[B,C,6] float64: sum p, sum t, sum p^2, sum t^2, sum p*t, sum w_lat (p-t)^2 per image (target top-left crop)"""
+    _dev(pred, F32, "pred"); _dev(target, F32, "target")
+    B, Cc, H, W = pred.shape
+    out = torch.empty(B, Cc, 6, dtype=torch.float64, device=pred.device)
+    _chk(lib().orbit2_eval_moments(_p(pred), _p(target), target.shape[2], target.shape[3], _p(lat_w), _p(out), B, Cc, H,
+                                   W, _stream()), "orbit2_eval_moments")
+    return out

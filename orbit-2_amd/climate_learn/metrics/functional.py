@@ -47,3 +47,43 @@ def image_gradient(pred, target, var_names: Optional[List[str]] = None, var_weig
     """mean((pred-target)^2 * w_var) + 0.1 * mean(|grad(target) - grad(pred)|) * mean(w_var)  (reference :59-114;
     forward-difference gradients as torchmetrics.functional.image.image_gradients defines them).  Scalar."""
     return _fused(pred, target, var_names, var_weights, True, None, 2)
+
+
+# ---- evaluation metrics (reference :236-324); one reduction kernel, the [B,C,6] -> [C+1] algebra on the host ----------
+def _moments(pred, target, lat_weights=None):
+    from .. import _hip
+    if isinstance(pred, torch.distributions.Normal):
+        pred = pred.loc
+    return _hip.eval_moments(pred.detach().float().contiguous(), target.detach().float().contiguous(),
+                             _lat(lat_weights, pred)), pred.shape[2] * pred.shape[3]
+
+
+def _with_aggregate(per_channel, aggregate_only):
+    agg = per_channel.mean()
+    return agg if aggregate_only else torch.cat((per_channel, agg.unsqueeze(0)))
+
+
+def rmse(pred, target, aggregate_only: bool = False, lat_weights=None, mask=None):
+    """sqrt(mean_hw((pred-target)^2 * w_lat)) per (b, c), mean over b, then over c (reference :236-255)."""
+    if mask is not None:
+        raise NotImplementedError("masked rmse is not on the downscaling path")
+    m, n = _moments(pred, target, lat_weights)
+    return _with_aggregate((m[..., 5] / n).sqrt().mean(0).float(), aggregate_only)
+
+
+def pearson(pred, target, aggregate_only: bool = False):
+    """cosine similarity of the mean-removed, channel-wise flattened [C, B*H*W] fields (reference :294-308)."""
+    m, n = _moments(pred, target)
+    s = m.sum(0)                                                   # [C,6] over the batch
+    N = n * pred.shape[0]
+    cov = s[:, 4] - s[:, 0] * s[:, 1] / N
+    vp = (s[:, 2] - s[:, 0] ** 2 / N).clamp_min(0).sqrt().clamp_min(1e-8)      # F.cosine_similarity's eps
+    vt = (s[:, 3] - s[:, 1] ** 2 / N).clamp_min(0).sqrt().clamp_min(1e-8)
+    return _with_aggregate((cov / (vp * vt)).float(), aggregate_only)
+
+
+def mean_bias(pred, target, aggregate_only: bool = False):
+    """mean(target) - mean(pred) per channel (reference :311-324)."""
+    m, n = _moments(pred, target)
+    s = m.sum(0)
+    return _with_aggregate(((s[:, 1] - s[:, 0]) / (n * pred.shape[0])).float(), aggregate_only)

@@ -7,7 +7,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .functional import bayesian_tv, image_gradient, mse
+from .functional import bayesian_tv, image_gradient, mean_bias, mse, pearson, rmse
 from .utils import MetricsMetaInfo, register
 
 
@@ -86,6 +86,32 @@ class PERCEPTUAL(Metric):
         return self.loss_fn.perceptual(pred, target)
 
 
+@register("rmse")
+class RMSE(Metric):
+    """reference metrics.py RMSE: unweighted root mean squared error (validation / test metric of the downscaling task)"""
+    def __call__(self, pred, target, mask=None):
+        return rmse(pred, target, self.aggregate_only, mask=mask)
+
+
+@register("pearson")
+class Pearson(Metric):
+    def __call__(self, pred, target):
+        return pearson(pred, target, self.aggregate_only)
+
+
+@register("mean_bias")
+class MeanBias(Metric):
+    def __call__(self, pred, target):
+        return mean_bias(pred, target, self.aggregate_only)
+
+
+@register("lat_rmse")
+class LatWeightedRMSE(LatitudeWeightedMetric):
+    def __call__(self, pred, target, mask=None):
+        self.cast_to_device(pred)
+        return rmse(pred, target, self.aggregate_only, self.lat_weights, mask)
+
+
 def _not_on_path(name):
     class _M(Metric):
         def __call__(self, *a, **k):
@@ -95,5 +121,5 @@ def _not_on_path(name):
     return register(name)(_M)
 
 
-for _n in ("rmse", "pearson", "mean_bias", "mae", "lat_rmse", "lat_acc", "acc"):
+for _n in ("mae", "lat_acc", "acc"):
     _not_on_path(_n)

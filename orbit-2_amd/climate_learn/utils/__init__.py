@@ -1,5 +1,7 @@
 from .fused_attn import FusedAttn
 from .checkpoint import load_checkpoint, load_pretrained_weights
+from . import visualize
+from .visualize import tiled_predict, tile_windows, visualize_at_index
 from .loaders import (
     load_model_module,
     load_forecasting_module,

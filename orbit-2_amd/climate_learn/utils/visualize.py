@@ -1,0 +1,149 @@
+"""Tiled inference + stitching (reference: utils/visualize.py:38-330, examples/visualize.py:340-478).
+
+The field is cut into div x div tiles, every tile is enlarged by a halo taken from its neighbours (edge tiles grow
+inwards only, so all tiles have the same size), the model runs on each enlarged tile, and only the tile's own
+interior is written into the stitched prediction.  Window arithmetic follows the reference line by line, with one
+decision: the reference shifts the ground-truth window of non-first tile rows by `top ** vmul` (:211, a typo for
+`top * vmul` -- the two agree only for top in {0, 1} x vmul = 1); the halo-consistent product is used here.
+Forward only (`torch.no_grad()`), everything stays on the device until the stitched arrays are returned."""
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+
+def halo(overlap: int) -> Tuple[int, int, int, int]:
+    """(top, bottom, left, right) halo in input pixels (reference :62-69; the grid is 2:1, so columns get twice the rows)"""
+    if overlap % 2 == 0:
+        top = bottom = overlap // 2
+        left = right = overlap // 2 * 2
+    else:
+        left = overlap // 2 * 2
+        right = (overlap // 2 + 1) * 2
+        top = overlap // 2
+        bottom = overlap // 2 + 1
+    return top, bottom, left, right
+
+
+def _axis_windows(n_in: int, n_out: int, div: int, lo: int, hi: int, mul: int):
+    """per tile index: (in window, out window, interior inside the in tile, interior inside the out tile, placement in / out)"""
+    res = []
+    for idx in range(div):
+        if div == 1:
+            res.append(((0, n_in), (0, n_out), (0, n_in), (0, n_out), (0, n_in), (0, n_out)))
+            continue
+        i1, i2 = n_in // div * idx, n_in // div * (idx + 1)
+        o1, o2 = n_out // div * idx, n_out // div * (idx + 1)
+        r_in, r_out = (i1, i2), (o1, o2)
+        if idx == 0:
+            i2 += lo
+            o2 += lo * mul
+        else:
+            i1 -= lo
+            o1 -= lo * mul
+        if idx == div - 1:
+            i1 -= hi
+            o1 -= hi * mul
+        else:
+            i2 += hi
+            o2 += hi * mul
+        if idx == 0:
+            t_in, t_out = (0, n_in // div), (0, n_out // div)
+        elif idx == div - 1:
+            t_in = (lo + hi, lo + hi + n_in // div)
+            t_out = ((lo + hi) * mul, (lo + hi) * mul + n_out // div)
+        else:
+            t_in = (lo, lo + n_in // div)
+            t_out = (lo * mul, lo * mul + n_out // div)
+        res.append(((i1, i2), (o1, o2), t_in, t_out, r_in, r_out))
+    return res
+
+
+def tile_windows(yinp: int, xinp: int, yout: int, xout: int, div: int, overlap: int) -> List[Dict]:
+    """the div*div tiles in the reference's (vindex, hindex) order"""
+    top, bottom, left, right = halo(overlap)
+    vmul, hmul = yout // yinp, xout // xinp
+    rows = _axis_windows(yinp, yout, div, top, bottom, vmul)
+    cols = _axis_windows(xinp, xout, div, left, right, hmul)
+    tiles = []
+    for v, (yi, yo, yit, yot, yir, yor) in enumerate(rows):
+        for h, (xi, xo, xit, xot, xir, xor_) in enumerate(cols):
+            tiles.append(dict(vindex=v, hindex=h, inp=(yi, xi), out=(yo, xo), crop_in=(yit, xit), crop_out=(yot, xot),
+                              place_in=(yir, xir), place_out=(yor, xor_)))
+    return tiles
+
+
+def tiled_predict(mm, x, y, in_variables, out_variables, div: int, overlap: int, clip=None):
+    """x: [B,V,yinp,xinp], y: [B,C,>=yout,>=xout] (normalised target; constant output channels are copied from it as
+    in training).  Returns the stitched prediction [B,C,yout,xout] (fp32, on x's device)."""
+    from ..trainer import clip_replace_constant
+    clip = clip or clip_replace_constant
+    B, _, yinp, xinp = x.shape
+    mag = mm.superres_mag
+    yout, xout = yinp * mag, xinp * mag
+    preds = torch.zeros(B, len(out_variables), yout, xout, dtype=torch.float32, device=x.device)
+    # the reference builds the data module with the same (div, overlap), so the model is data_config'd to the tile
+    # size before it gets here; do that rebinding (no weights change) when the caller has not
+    saved = None
+    with torch.no_grad():
+        for t in tile_windows(yinp, xinp, yout, xout, div, overlap):
+            (yi1, yi2), (xi1, xi2) = t["inp"]
+            (yo1, yo2), (xo1, xo2) = t["out"]
+            xdiv = x[:, :, yi1:yi2, xi1:xi2].contiguous()
+            ydiv = y[:, :, yo1:yo2, xo1:xo2]
+            if hasattr(mm, "data_config") and tuple(getattr(mm, "img_size", xdiv.shape[2:])) != tuple(xdiv.shape[2:]):
+                if saved is None:
+                    saved = (mm.spatial_resolution, mm.img_size, mm.in_channels, mm.out_channels)
+                mm.data_config(mm.spatial_resolution, tuple(xdiv.shape[2:]), mm.in_channels, mm.out_channels)
+            pred = mm.forward(xdiv, in_variables, out_variables)
+            pred = clip(ydiv, pred, out_variables)
+            (ya, yb), (xa, xb) = t["crop_out"]
+            (ra, rb), (ca, cb) = t["place_out"]
+            preds[:, :, ra:rb, ca:cb] = pred[:, :, ya:yb, xa:xb].float()
+    if saved is not None:
+        mm.data_config(*saved)
+    return preds
+
+
+def visualize_at_index(mm, dm, dm_vis, out_list, in_transform, out_transform, variable, src, device, div, overlap, index=0,
+                       tensor_par_size=1, tensor_par_group=None, save_png: bool = True, prefix: str = ""):
+    """Stitched input / prediction / ground truth of test sample `index` for `variable` (reference :38-490; the PNG
+    dumps are optional here).  Returns {'inputs', 'preds', 'groundtruths'} as numpy arrays, north-up for
+    ERA5 / PRISM / DAYMET sources like the reference's per-tile flips."""
+    out_channel = dm.out_vars.index(variable)
+    in_channel = dm.in_vars.index(variable)
+    counter, adj_index, batch = 0, None, None
+    for batch in dm_vis.test_dataloader():
+        bs = batch[0].shape[0]
+        if index in range(counter, counter + bs):
+            adj_index = index - counter
+            break
+        counter += bs
+    if adj_index is None:
+        raise IndexError("test sample %d not found" % index)
+    x, y, in_variables, out_variables = batch[:4]
+    x, y = x.to(device), y.to(device)
+    preds = tiled_predict(mm, x, y, in_variables, out_variables, div, overlap)
+    yout, xout = preds.shape[2:]
+    inp = in_transform(x[adj_index, in_channel].repeat(len(out_list), 1, 1))[out_channel]
+    prd = out_transform(preds[adj_index])[out_channel]
+    gt = out_transform(y[adj_index, :, :yout, :xout])[out_channel]
+    res = {"inputs": inp.detach().cpu().numpy(), "preds": prd.detach().cpu().numpy(),
+           "groundtruths": gt.detach().cpu().numpy()}
+    if "ERA5" in src or src == "PRISM" or "DAYMET" in src:
+        res = {k: np.flip(v, 0).copy() for k, v in res.items()}
+    if save_png:
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+            for name, key in (("input", "inputs"), ("prediction", "preds"), ("groundtruth", "groundtruths")):
+                img = res[key]
+                plt.figure(figsize=(max(img.shape[1] / 100, 2), max(img.shape[0] / 100, 1)))
+                plt.imshow(img, cmap="coolwarm", vmin=float(img.min()), vmax=float(img.max()))
+                plt.savefig("%s%d_%s.png" % (prefix, rank, name))
+                plt.close()
+        except ImportError:
+            pass
+    return res

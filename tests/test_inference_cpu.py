@@ -1,0 +1,77 @@
+"""CPU tests of the tiled-inference window arithmetic and stitching (reference utils/visualize.py:60-240)."""
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.mark.parametrize("div,overlap", [(1, 0), (2, 2), (2, 4), (4, 2), (3, 4), (2, 3)])
+def test_tile_windows_partition_and_halo(div, overlap):
+    from climate_learn.utils.visualize import tile_windows, halo
+    yinp, xinp, mag = 48, 96, 4
+    yout, xout = yinp * mag, xinp * mag
+    top, bottom, left, right = halo(overlap)
+    tiles = tile_windows(yinp, xinp, yout, xout, div, overlap)
+    assert len(tiles) == div * div
+    cover_in = np.zeros((yinp, xinp), dtype=np.int32)
+    cover_out = np.zeros((yout, xout), dtype=np.int32)
+    sizes = set()
+    for t in tiles:
+        (yi1, yi2), (xi1, xi2) = t["inp"]
+        (yo1, yo2), (xo1, xo2) = t["out"]
+        assert 0 <= yi1 < yi2 <= yinp and 0 <= xi1 < xi2 <= xinp
+        assert (yo1, yo2, xo1, xo2) == (yi1 * mag, yi2 * mag, xi1 * mag, xi2 * mag)
+        sizes.add((yi2 - yi1, xi2 - xi1))
+        (ya, yb), (xa, xb) = t["crop_in"]
+        (ra, rb), (ca, cb) = t["place_in"]
+        assert (yi1 + ya, yi1 + yb, xi1 + xa, xi1 + xb) == (ra, rb, ca, cb)      # interior lands where it came from
+        cover_in[ra:rb, ca:cb] += 1
+        (ya, yb), (xa, xb) = t["crop_out"]
+        (ra, rb), (ca, cb) = t["place_out"]
+        assert (yo1 + ya, yo1 + yb, xo1 + xa, xo1 + xb) == (ra, rb, ca, cb)
+        cover_out[ra:rb, ca:cb] += 1
+    assert (cover_in == 1).all() and (cover_out == 1).all()                      # exact partition
+    if div > 1:
+        assert sizes == {(yinp // div + top + bottom, xinp // div + left + right)}  # every tile has the same size
+
+
+def test_halo_values_follow_the_reference_rule():
+    from climate_learn.utils.visualize import halo
+    assert halo(0) == (0, 0, 0, 0) and halo(2) == (1, 1, 2, 2) and halo(4) == (2, 2, 4, 4)
+    assert halo(3) == (1, 2, 2, 4) and halo(1) == (0, 1, 0, 2)
+
+
+@pytest.mark.parametrize("div,overlap", [(1, 0), (2, 4), (4, 2)])
+def test_stitching_a_local_operator_reproduces_the_untiled_result(div, overlap):
+    """with a purely local stand-in model (nearest x4 upsampling + a 3x3 box blur whose support fits in the halo),
+    the stitched field equals the untiled one everywhere: interiors are cropped and placed correctly"""
+    from types import SimpleNamespace
+    from climate_learn.utils.visualize import tiled_predict
+    import torch.nn.functional as F
+
+    def fwd(x, in_vars, out_vars):
+        up = x[:, :2].repeat_interleave(4, 2).repeat_interleave(4, 3)
+        return F.avg_pool2d(F.pad(up, (1, 1, 1, 1), mode="replicate"), 3, 1)
+
+    mm = SimpleNamespace(superres_mag=4, forward=fwd)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 32, 64, generator=g)
+    y = torch.zeros(2, 2, 130, 259)
+    full = fwd(x, None, None)
+    got = tiled_predict(mm, x, y, ["a"] * 5, ["p", "q"], div, overlap, clip=lambda yd, pred, ov: pred)
+    if div == 1:
+        assert torch.equal(got, full)
+    else:
+        # the blur touches 1 output pixel beyond a tile edge; interiors are >= 4 output pixels away from a cut
+        assert torch.allclose(got, full, atol=1e-6)
+
+
+def test_denormalize_leaves_precipitation_alone():
+    from types import SimpleNamespace
+    from climate_learn.transforms import Denormalize
+    dm = SimpleNamespace(get_out_transforms=lambda: {"total_precipitation_24hr": SimpleNamespace(mean=3.0, std=2.0),
+                                                     "2m_temperature_min": SimpleNamespace(mean=280.0, std=10.0)})
+    d = Denormalize(dm)
+    x = torch.ones(2, 2, 3, 4)
+    out = d(x)
+    assert torch.equal(out[:, 0], x[:, 0]) and torch.allclose(out[:, 1], torch.full((2, 3, 4), 290.0))
+    assert torch.allclose(d(x[0])[1], torch.full((3, 4), 290.0))          # [C,H,W] input like the reference's use

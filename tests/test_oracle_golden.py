@@ -193,3 +193,16 @@ def test_flop_model_matches_survey():
     assert abs(f / 2.950e13 - 1) < 2e-3
     f = O.forward_flops(512, 23, 1024, 8, 4, 3, 32, 64, 16)
     assert abs(f / 1.679e11 - 1) < 2e-3
+
+
+def test_eval_metrics_match_reference(golden_dir):
+    """rmse / lat-weighted rmse / pearson / mean_bias against the reference's own functions (make_golden_eval.py)"""
+    z = np.load(os.path.join(golden_dir, "eval_metrics.npz"))
+    pred, target = torch.from_numpy(z["pred"]), torch.from_numpy(z["target"])
+    lw = O.lat_weights(z["lat"])
+    for name, got in (("rmse", O.rmse(pred, target)), ("lat_rmse", O.rmse(pred, target, False, lw)),
+                      ("pearson", O.pearson(pred, target)), ("mean_bias", O.mean_bias(pred, target))):
+        assert np.allclose(got.numpy(), z[name], rtol=2e-5, atol=2e-6), name
+    assert np.allclose(float(O.rmse(pred, target, True)), z["rmse.agg"], rtol=2e-5)
+    assert np.allclose(float(O.pearson(pred, target, True)), z["pearson.agg"], rtol=2e-5)
+    assert np.allclose(float(O.mean_bias(pred, target, True)), z["mean_bias.agg"], rtol=2e-5, atol=2e-6)
