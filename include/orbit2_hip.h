@@ -30,8 +30,8 @@ int orbit2_abi_version(void);
  * input-gradient (a_kc=1,b_kc=0) and weight-gradient (a_kc=b_kc=0) forms.
  * Epilogue order: +bias -> save_pre -> GELU -> [+residual if res_first] -> dropout ->
  *   *gelu'(dgelu_pre) -> *rowscale[m / rows_per_scale] -> [+residual] -> C = beta*C + v.
- * Requirements: K % 64 == 0, N % 8 == 0, M % 8 == 0 unless a_kc (any M then), lda/ldb/ldc % 8 == 0, 16-byte aligned
- * bases. */
+ * Requirements: N % 8 == 0; M % 8 == 0 unless a_kc (any M then); K % 8 == 0 if an operand is K-contiguous, any K when
+ * both are K-strided (the weight-gradient form: K = tokens); lda/ldb/ldc % 8 == 0, 16-byte aligned bases. */
 typedef struct {
   const void* A; const void* B; void* C;
   int M, N, K;

@@ -18,8 +18,11 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
 
+// 16 zero bytes every lane may fetch: the source of LDS-DMA pieces that lie past the end of the contraction (K tail)
+__device__ __attribute__((aligned(16))) const unsigned int o2_zero16[4] = {0u, 0u, 0u, 0u};
+
 template <bool KC>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0,
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int kmax,
                                            char* tile, int wave, int lane) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -31,6 +34,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
       int gr = r0 + row;
       gr = gr < rmax ? gr : rmax - 1;
       src = G + (size_t)gr * ld + k0 + chunk * 8;
+      if (k0 + chunk * 8 >= kmax) src = reinterpret_cast<const bf16_t*>(o2_zero16);
     } else {
       const int krow = i * 4 + (lane >> 4);
       const int cp = lane & 15;
@@ -39,6 +43,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
       int col = r0 + chunk * 8;
       col = col <= rmax - 8 ? col : rmax - 8;
       src = G + (size_t)(k0 + krow) * ld + col;
+      if (k0 + krow >= kmax) src = reinterpret_cast<const bf16_t*>(o2_zero16);
     }
     glds16(src, tile + i * 1024);
   }
@@ -269,9 +274,9 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
-  stage_tile<A_KC>(A, lda, m0, M, 0, smem, wave, lane);
-  stage_tile<B_KC>(B, ldb, n0, N, 0, smem + TILE_BYTES, wave, lane);
+  const int nk = (K + BK - 1) / BK;      // a ragged K tail is staged from the zero page
+  stage_tile<A_KC>(A, lda, m0, M, 0, K, smem, wave, lane);
+  stage_tile<B_KC>(B, ldb, n0, N, 0, K, smem + TILE_BYTES, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -281,8 +286,8 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
     char* sb = sa + TILE_BYTES;
     if (kt + 1 < nk) {
       char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile<A_KC>(A, lda, m0, M, (kt + 1) * BK, na, wave, lane);
-      stage_tile<B_KC>(B, ldb, n0, N, (kt + 1) * BK, na + TILE_BYTES, wave, lane);
+      stage_tile<A_KC>(A, lda, m0, M, (kt + 1) * BK, K, na, wave, lane);
+      stage_tile<B_KC>(B, ldb, n0, N, (kt + 1) * BK, K, na + TILE_BYTES, wave, lane);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -616,7 +621,12 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return O2_ERR_ARG;
   // rows of a K-contiguous operand are clamped at staging and masked at the store, so M is free there; an operand
   // stored K-strided is fetched in 8-element pieces along its M / N axis; stores are 8 (bf16) / 4 (fp32) n wide
-  if (a->K % BK || a->N % 8 || (!a->a_kc && a->M % 8) || a->lda % 8 || a->ldb % 8 || a->ldc % 4) return O2_ERR_ARG;
+  // K: a K-contiguous operand is fetched in 8-element pieces along k (K % 8); K-strided operands take any K (whole
+  // rows).  The 128-tile kernel stages a ragged K tail from a zero page; the ring kernel needs K % 32 == 0.
+  if (((a->a_kc || a->b_kc) && a->K % 8) || a->N % 8 || (!a->a_kc && a->M % 8) || a->lda % 8 || a->ldb % 8 ||
+      a->ldc % 4)
+    return O2_ERR_ARG;
+  if (a->tile_hint == 256 && a->K % BK2) return O2_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;

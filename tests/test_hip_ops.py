@@ -79,6 +79,21 @@ def test_gemm_any_row_count_when_a_is_k_contiguous(hip, M, tile):
         hip.gemm(bf(A.t().contiguous()).cuda(), bf(B).cuda(), guard, M, N, K, M + (-M) % 8, K, N, a_kc=False)
 
 
+@pytest.mark.parametrize("form,K", [("tn", 70), ("tn", 201), ("tn", 64 + 35), ("nt", 72), ("nn", 136), ("tt", 40)])
+def test_gemm_ragged_contraction_length(hip, form, K):
+    """K need not be a multiple of the 64-wide k-step: the tail is staged from a zero page (weight-gradient form:
+    K = number of tokens, any value; K-contiguous operands: K % 8 == 0)"""
+    M, N = 136, 200
+    g = torch.Generator().manual_seed(K)
+    A, B = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g))
+    a_kc, b_kc = form[0] == "n", form[1] == "t"
+    Ad = bf(A if a_kc else A.t().contiguous()).cuda()
+    Bd = bf(B if b_kc else B.t().contiguous()).cuda()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(Ad, Bd, out, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc)
+    assert nerr(out, A @ B.t()) < 2e-5
+
+
 @pytest.mark.parametrize("form", ["tn", "nt"])
 def test_gemm_grouped_matches_single_launches(hip, form):
     """one grouped launch == the same problems launched one by one (same kernel, same tile walk: bit-identical),

@@ -174,6 +174,29 @@ def test_daymet_like_three_outputs_perceptual_loss():
         assert nerr(p.grad, sdo[name].grad) < 6e-2, name
 
 
+def test_odd_token_count_grid_trains():
+    """a 10 x 20 input grid gives L = 50 tokens per sample (B*L = 150): ragged attention tiles, GEMM rows not a
+    multiple of 8 and a weight-gradient contraction that is not a multiple of the k-step; loss + gradients vs the oracle
+    (grids stay 2:1 -- the reference's pos-embed resampling assumes it, pos_embed.py:108-111)"""
+    from climate_learn.testing import build_pair, nerr
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.trainer import training_step
+    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2, grid=(10, 20), B=3, seed=11)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).eval()
+    vw = {"total_precipitation_24hr": 1.0}
+    loss = training_step((x, y, in_vars, out_vars), 0, model, dev, vw, Bayesian_TV(aggregate_only=True))
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 2e-2
+    for name, p in (("head.0.weight", model.head[0].weight), ("blocks.1.mlp.fc2.weight", model.blocks[1].mlp.fc2.weight),
+                    ("blocks.0.attn.qkv.weight", model.blocks[0].attn.qkv.weight),
+                    ("blocks.0.attn.proj.bias", model.blocks[0].attn.proj.bias), ("blocks.1.norm1.weight", model.blocks[1].norm1.weight)):
+        assert nerr(p.grad, sdo[name].grad) < 6e-2, name
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
