@@ -71,8 +71,37 @@ def traffic(fetch_csv, write_csv, out):
     json.dump(res, open(out, "w"), indent=1)
 
 
+def mfma(path, out):
+    """SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE pass -> matrix-pipe utilisation per kernel:
+    busy cycles summed over the chip's 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs * 1024); the effective clock is
+    GRBM_GUI_ACTIVE / 8 / kernel duration (MI355X_MICROARCH.md, DVFS give-back)."""
+    rows = list(csv.DictReader(open(path)))
+    per = collections.OrderedDict()
+    for r in rows:
+        d = per.setdefault(r["Dispatch_Id"], {"k": short(r["Kernel_Name"]),
+                                              "ns": float(r["End_Timestamp"]) - float(r["Start_Timestamp"])})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    agg = collections.OrderedDict()
+    for d in per.values():
+        if "GRBM_GUI_ACTIVE" not in d or "SQ_VALU_MFMA_BUSY_CYCLES" not in d:
+            continue
+        a = agg.setdefault(d["k"], [0.0, 0.0, 0.0, 0])
+        a[0] += d["SQ_VALU_MFMA_BUSY_CYCLES"]; a[1] += d["GRBM_GUI_ACTIVE"]; a[2] += d["ns"]; a[3] += 1
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (source: %s)\n" % path.split("/")[-1])
+        f.write("%-58s %6s %10s %12s %10s\n" % ("kernel", "calls", "total_ms", "mfma_busy", "clock_GHz"))
+        for k, (busy, gui, ns, n) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+            if busy <= 0:
+                continue
+            util = busy / (gui / 8.0 * 1024.0)
+            f.write("%-58s %6d %10.3f %11.1f%% %10.2f\n" % (k[:58], n, ns / 1e6, 100 * util, gui / 8.0 / ns))
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
+    if mode == "mfma":
+        mfma(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     if mode == "traffic":
         traffic(*sys.argv[2:5])
     else:
