@@ -24,6 +24,7 @@ __device__ __attribute__((aligned(16))) const unsigned int o2_zero16[4] = {0u, 0
 template <bool KC>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int kmax,
                                            char* tile, int wave, int lane) {
+  const bool tail = k0 + BK > kmax;   // wave-uniform: only the last k-step of a ragged K pays the per-lane redirect
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int i = wave * 4 + t;  // LDS-DMA instruction id, 0..15 (1 KiB each)
@@ -34,7 +35,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
       int gr = r0 + row;
       gr = gr < rmax ? gr : rmax - 1;
       src = G + (size_t)gr * ld + k0 + chunk * 8;
-      if (k0 + chunk * 8 >= kmax) src = reinterpret_cast<const bf16_t*>(o2_zero16);
+      if (tail && k0 + chunk * 8 >= kmax) src = reinterpret_cast<const bf16_t*>(o2_zero16);
     } else {
       const int krow = i * 4 + (lane >> 4);
       const int cp = lane & 15;
@@ -43,7 +44,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
       int col = r0 + chunk * 8;
       col = col <= rmax - 8 ? col : rmax - 8;
       src = G + (size_t)(k0 + krow) * ld + col;
-      if (k0 + krow >= kmax) src = reinterpret_cast<const bf16_t*>(o2_zero16);
+      if (tail && k0 + krow >= kmax) src = reinterpret_cast<const bf16_t*>(o2_zero16);
     }
     glds16(src, tile + i * 1024);
   }
