@@ -107,13 +107,16 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
     // S^T[kb] = K_kb . Q^T   (rows = keys in registers, column = query on the lane)
     f32x16 s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    // the two key blocks' chains are interleaved: a K fragment is consumed two MFMAs after the previous one of its
+    // chain, so its LDS read has twice the time to land
 #pragma unroll
-      for (int ds = 0; ds < C::NDS; ++ds)
+    for (int ds = 0; ds < C::NDS; ++ds)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
         s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s[kb]);
-    }
     if (RAGGED && t == nt - 1 && (L & 63)) {   // keys past the end of a ragged sequence get no weight
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -405,16 +408,36 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
     }
     const float* s_lse = sstat + (cur * 2 + 0) * 64;
     const float* s_dlt = sstat + (cur * 2 + 1) * 64;
+    // the dV-only pass has a single chain per query block (S = Q.K^T): run both blocks' chains interleaved so each
+    // Q fragment's LDS read gets two MFMAs of time to land (the dK pass interleaves its S and dP chains instead)
+    f32x16 s_pre[(!DO_DK) ? 2 : 1];
+    if (!DO_DK) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_pre[qb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          s_pre[qb] = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s_pre[qb]);
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       // S[q x key] = Q . K^T, dP[q x key] = dO . V^T  (rows = queries in registers, column = key on the lane)
       f32x16 s, dp;
+      if (DO_DK) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-      for (int ds = 0; ds < C::NDS; ++ds) {
-        s = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s);
-        if (DO_DK) dp = MFMA32(row_frag<D>(sdo, qb * 32 + (lane & 31), ds, hq), vf[ds], dp);
+        for (int ds = 0; ds < C::NDS; ++ds) {
+          s = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s);
+          dp = MFMA32(row_frag<D>(sdo, qb * 32 + (lane & 31), ds, hq), vf[ds], dp);
+        }
+      } else {
+        s = s_pre[qb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
       }
       // dropout: one hash covers 4 consecutive keys = the 4 lanes of a quad; each lane hashes 4 of the 16
       // query rows (rows r with (r&3) == lane&3) and the quad shares them by DPP broadcast.
