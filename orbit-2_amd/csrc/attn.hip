@@ -43,16 +43,20 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {
 
 // dropout on a 32x32 tile whose lane-local axis (registers) runs along KEYS: registers 4t..4t+3 are keys
 // kbase + 8t + 4h + {0..3} of query row qrow -> one hash per 4 registers.
-// rowq = (bh*L+q)*(Lp/4) + h is the lane's group index at key 0 (Lp = L rounded up to 4); the per-tile part
-// (kbase/4 + 2t) is wave-uniform, so each hash index costs one 64-bit add.
-__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint64_t seed, uint64_t rowq, int kbase, unsigned thr) {
+// kh4[t] = key-group hash of keys kbase + 8t + 4h + {0..3} (from the tile's LDS table, see stage_keyhash)
+__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint32_t rowhash, const u32x4& kh4, unsigned thr) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint64_t idx = rowq + (uint64_t)((kbase >> 2) + 2 * t);
-    const uint32_t hh = o2_hash64(seed, idx);
+    const uint32_t hh = o2_attn_mix(rowhash, kh4[t]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) p[4 * t + e] = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : 0.f;
   }
+}
+
+// Key-group hashes of one 64-key tile (16 groups), written by 16 lanes of wave 0 one tile ahead.  Entry order:
+// group i = 2j + h (j = kb*4 + t) is stored at h*8 + j, so half-wave h reads its 8 values as two 16-byte pieces.
+__device__ __forceinline__ void stage_keyhash(uint32_t* skh, uint64_t seed, int tile, int tid) {
+  if (tid < 16) skh[(tid & 1) * 8 + (tid >> 1)] = o2_attn_keyhash(seed, (uint32_t)(tile * 16 + tid));
 }
 
 // =============================================================================================
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
                                                           unsigned thr, float dscale, uint64_t seed) {
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // [2 stages][K | V]
+  __shared__ __attribute__((aligned(16))) uint32_t skh[2][16];      // [stage] key-group hashes of the tile (dropout)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;  // MFMA half
@@ -88,11 +93,12 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  const uint64_t rowq = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)((L + 3) >> 2) + (uint64_t)hq;
+  const uint32_t rowhash = DROP ? o2_attn_rowhash(seed, (uint64_t)(b * H + head) * L + (uint64_t)qrow) : 0u;
 
   const int nt = (L + 63) / 64;
   stage64<D, RAGGED>(kbase, tstride, smem, wave, lane, L);
   stage64<D, RAGGED>(vbase, tstride, smem + C::TILE, wave, lane, L);
+  if (DROP) stage_keyhash(skh[0], seed, 0, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
       stage64<D, RAGGED>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
       stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
+      if (DROP) stage_keyhash(skh[cur ^ 1], seed, t + 1, tid);
     }
     // S^T[kb] = K_kb . Q^T   (rows = keys in registers, column = query on the lane)
     f32x16 s[2];
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
     l_run = l_run * alpha + psum;
     if (DROP) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) drop_keys_in_regs(s[kb], seed, rowq, t * 64 + kb * 32, thr);
+      for (int kb = 0; kb < 2; ++kb)
+        drop_keys_in_regs(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
     }
     // O^T[db] += V^T . P^T
 #pragma unroll
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
                                                              unsigned thr, float dscale, uint64_t seed) {
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t skh[2][16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
   const size_t sidx = ((size_t)(b * H + head)) * L + qrow;
   const float lse2 = lse[sidx] * 1.4426950408889634f;
   const float dlt = DROP ? delta[sidx] / dscale : delta[sidx];   // dscale folded into the final scale
-  const uint64_t rowq = ((uint64_t)(b * H + head) * L + (uint64_t)qrow) * (uint64_t)((L + 3) >> 2) + (uint64_t)hq;
+  const uint32_t rowhash = DROP ? o2_attn_rowhash(seed, (uint64_t)(b * H + head) * L + (uint64_t)qrow) : 0u;
 
   f32x16 dq[C::NDB];
 #pragma unroll
@@ -270,6 +279,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
   const int nt = (L + 63) / 64;
   stage64<D, RAGGED>(kbase, tstride, smem, wave, lane, L);
   stage64<D, RAGGED>(vbase, tstride, smem + C::TILE, wave, lane, L);
+  if (DROP) stage_keyhash(skh[0], seed, 0, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -280,6 +290,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
       stage64<D, RAGGED>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
       stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
+      if (DROP) stage_keyhash(skh[cur ^ 1], seed, t + 1, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
         s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s);
         dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], dp);
       }
-      if (DROP) drop_keys_in_regs(dp, seed, rowq, t * 64 + kb * 32, thr);
+      if (DROP) drop_keys_in_regs(dp, rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
       const bool tail = RAGGED && (t == nt - 1) && (L & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
                                                               unsigned thr, float dscale, uint64_t seed) {
   using C = Cfg<D>;
   constexpr bool DO_DK = WHICH != 2, DO_DV = WHICH != 1;
-  __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 2 * 64 * 4];  // [2][Q|dO] + [2][lse2|delta]
+  __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 3 * 64 * 4];  // [2][Q|dO] + [2][lse2|delta|row hash]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;
@@ -376,8 +387,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 
   const size_t sbase = ((size_t)(b * H + head)) * L;
   const uint64_t bh = (uint64_t)(b * H + head);
-  const uint32_t lq = (uint32_t)((L + 3) >> 2);   // mask rows are padded to a multiple of 4 keys
-  const uint32_t hoff = (uint32_t)((lane & 3) + 4 * hq) * lq + (uint32_t)(krow >> 2);
+  const uint32_t keyhash = DROP ? o2_attn_keyhash(seed, (uint32_t)(krow >> 2)) : 0u;   // this lane's key group
   const int nt = (L + 63) / 64;
   auto stage_stats = [&](int t, int buf) {
     if (tid < 128) {
@@ -388,7 +398,10 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
                   : lse[sbase + t * 64 + i] * 1.4426950408889634f;
       else
         v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
-      sstat[(buf * 2 + which) * 64 + i] = v;
+      sstat[(buf * 3 + which) * 64 + i] = v;
+    } else if (DROP && tid < 192) {   // dropout: hashes of the tile's 64 query rows
+      const int i = tid & 63;
+      reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
     }
   };
   stage64<D, RAGGED>(qbase, tstride, smem, wave, lane, L);
@@ -406,8 +419,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
       stage64<D, RAGGED>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane, L - (t + 1) * 64);
       stage_stats(t + 1, cur ^ 1);
     }
-    const float* s_lse = sstat + (cur * 2 + 0) * 64;
-    const float* s_dlt = sstat + (cur * 2 + 1) * 64;
+    const float* s_lse = sstat + (cur * 3 + 0) * 64;
+    const float* s_dlt = sstat + (cur * 3 + 1) * 64;
+    const uint32_t* s_rh = reinterpret_cast<const uint32_t*>(sstat) + (cur * 3 + 2) * 64;
     // the dV-only pass has a single chain per query block (S = Q.K^T): run both blocks' chains interleaved so each
     // Q fragment's LDS read gets two MFMAs of time to land (the dK pass interleaves its S and dP chains instead)
     f32x16 s_pre[(!DO_DK) ? 2 : 1];
@@ -439,18 +453,17 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = 0.f;
       }
-      // dropout: one hash covers 4 consecutive keys = the 4 lanes of a quad; each lane hashes 4 of the 16
-      // query rows (rows r with (r&3) == lane&3) and the quad shares them by DPP broadcast.
+      // dropout: one mask word covers 4 consecutive keys = the 4 lanes of a quad; each lane mixes 4 of the 16
+      // query rows (rows r with (r&3) == lane&3: their hashes come from the tile's LDS table) with its key-group
+      // hash and the quad shares the words by DPP broadcast.
       const int kbyte = 8 * (krow & 3);
-      // hash index = (wave-uniform 64-bit part) + (per-lane 32-bit part hoff)
-      const uint64_t hrow0 = (bh * (uint64_t)L + (uint64_t)(t * 64 + qb * 32)) * (uint64_t)lq;
       // per-row statistics: registers 4g..4g+3 are 4 consecutive query rows -> one 16-byte LDS read per group,
       // fetched just in time (keeps 32 VGPRs out of the MFMA section's live set)
       uint32_t hmine[4] = {0u, 0u, 0u, 0u};
       if (DROP) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
-          hmine[g4] = o2_hash64(seed, hrow0 + (uint64_t)(8 * g4) * (uint64_t)lq + (uint64_t)hoff);
+          hmine[g4] = o2_attn_mix(s_rh[qb * 32 + 8 * g4 + 4 * hq + (lane & 3)], keyhash);
       }
       f32x16 pd;  // P after dropout (for dV)
 #pragma unroll

@@ -57,6 +57,24 @@ __device__ __forceinline__ uint32_t o2_hash64(uint64_t seed, uint64_t idx) {
   return o2_hash((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)idx, (uint32_t)(idx >> 32));
 }
 
+// ---- attention-probability dropout: a factored hash ------------------------------------------------------------
+// keep(row, key) is byte (key & 3) of  mix(R(row) ^ K(key >> 2))  >= thr, with R and K full o2_hash64 values of the
+// global query row (b*H + head)*L + q and of the key group.  In every kernel one of the two factors is fixed per lane
+// for the whole launch (the query row in the forward / dQ kernels, the key group in the dK / dV kernels) and the other
+// is shared by the wave, so the per-element-group cost is one xor, one multiply and one xor-shift instead of a 64-bit
+// index and two multiplies.  The single multiply after the xor removes the GF(2) structure of R ^ K (without it the
+// four masks of any 2x2 row/key-group rectangle would be linearly dependent); tests/hashmask.py holds the numpy
+// replica and the statistics the choice was checked with.
+#define O2_ATTN_KEY_SALT 0x85EBCA6B9E3779B9ull
+__device__ __forceinline__ uint32_t o2_attn_rowhash(uint64_t seed, uint64_t row) { return o2_hash64(seed, row); }
+__device__ __forceinline__ uint32_t o2_attn_keyhash(uint64_t seed, uint32_t kg) {
+  return o2_hash64(seed ^ O2_ATTN_KEY_SALT, (uint64_t)kg);
+}
+__device__ __forceinline__ uint32_t o2_attn_mix(uint32_t r, uint32_t k) {
+  uint32_t x = (r ^ k) * 0x9E3779B1u;
+  return x ^ (x >> 16);
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));

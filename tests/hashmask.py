@@ -30,3 +30,22 @@ def keep_mask(seed: int, n_elems: int, p: float):
     h = o2_hash64(seed, i >> np.uint64(2))
     byte = (h >> ((i & np.uint64(3)) * np.uint64(8))) & np.uint64(0xFF)
     return (byte >= np.uint64(thr)).astype(np.float32), 256.0 / (256.0 - thr)
+
+
+ATTN_KEY_SALT = 0x85EBCA6B9E3779B9
+
+
+def attn_keep_mask(seed: int, BH: int, L: int, p: float):
+    """[BH, L(query), L(key)] keep mask of the attention-probability dropout (csrc/common.h: o2_attn_*):
+    byte (key & 3) of mix(R(row) ^ K(key >> 2)) >= thr with R = o2_hash64(seed, bh*L + q),
+    K = o2_hash64(seed ^ SALT, key >> 2), mix(r, k) = x ^ (x >> 16), x = ((r ^ k) * 0x9E3779B1) mod 2^32."""
+    thr = int(p * 256.0 + 0.5)
+    if thr == 0:
+        return np.ones((BH, L, L), dtype=np.float32), 1.0
+    R = o2_hash64(seed, np.arange(BH * L, dtype=np.uint64)).reshape(BH, L, 1)
+    K = o2_hash64((seed ^ ATTN_KEY_SALT) & 0xFFFFFFFFFFFFFFFF, np.arange((L + 3) // 4, dtype=np.uint64))
+    key = np.arange(L, dtype=np.uint64)
+    x = ((R ^ K[(key >> np.uint64(2)).astype(np.int64)][None, None, :]) * np.uint64(0x9E3779B1)) & M32
+    x ^= x >> np.uint64(16)
+    byte = (x >> ((key & np.uint64(3)) * np.uint64(8))[None, None, :]) & np.uint64(0xFF)
+    return (byte >= np.uint64(thr)).astype(np.float32), 256.0 / (256.0 - thr)

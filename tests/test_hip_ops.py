@@ -11,7 +11,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import orbit2_oracle as O
-from tests.hashmask import keep_mask
+from tests.hashmask import attn_keep_mask, keep_mask
 
 
 @pytest.fixture(scope="module")
@@ -219,9 +219,8 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
     seed = 99887766
     mask, sc = None, 1.0
     if p > 0:
-        Lp = (L + 3) // 4 * 4              # mask rows are padded to a multiple of 4 keys (csrc/attn.hip)
-        m, sc = keep_mask(seed, B * H * L * Lp, p)
-        mask = torch.from_numpy(m).view(B, H, L, Lp)[..., :L]
+        m, sc = attn_keep_mask(seed, B * H, L, p)
+        mask = torch.from_numpy(m).view(B, H, L, L)
     ref = _attn_ref(qkv, B, L, H, d, mask, sc)
     ref.backward(do)
     qd = bf(qkv.detach()).cuda()

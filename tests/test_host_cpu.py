@@ -91,6 +91,26 @@ def test_hash_replica_known_answers():
     assert abs(m.mean() - (1 - 26 / 256)) < 5e-3 and abs(sc - 256 / 230) < 1e-12
 
 
+def test_attention_dropout_mask_statistics():
+    """the factored attention mask hash (one multiply after R(row) ^ K(key group)) must look like independent
+    Bernoulli draws: keep rate, neighbour correlations along both axes, the parity of 2x2 row/key-group rectangles
+    (the structure a plain xor of two hashes would leave) and the per-row / per-key keep-count variances"""
+    from tests.hashmask import attn_keep_mask
+    m, sc = attn_keep_mask(0x1234567ABCDEF, 2, 1024, 0.1)
+    m = m.reshape(-1, m.shape[-1]).astype(np.float64)               # [rows, keys]
+    keep = 1 - 26 / 256
+    assert abs(m.mean() - keep) < 2e-3 and abs(sc - 256 / 230) < 1e-12
+    c = lambda a, b: float(((a - keep) * (b - keep)).mean() / (keep * (1 - keep)))
+    tol = 5 / np.sqrt(m.size)                                        # ~5 sigma of an independent field
+    assert abs(c(m[:-1], m[1:])) < tol and abs(c(m[:, :-1], m[:, 1:])) < tol and abs(c(m[:, :-4], m[:, 4:])) < tol
+    par = (m[:-1, :-4] + m[1:, 4:] + m[:-1, 4:] + m[1:, :-4]) % 2
+    q = 1 - keep
+    assert abs(par.mean() - (1 - (1 - 2 * q) ** 4) / 2) < 3e-3
+    n = m.shape[1]
+    assert 0.85 < m.sum(1).var() / (n * keep * (1 - keep)) < 1.15
+    assert 0.85 < m.sum(0).var() / (m.shape[0] * keep * (1 - keep)) < 1.15
+
+
 def test_checkpoint_pos_embed_interpolation_matches_oracle():
     """interpolate_pos_embed (reference components/pos_embed.py:75-100) on a checkpoint dict, vs the oracle."""
     from types import SimpleNamespace
