@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--recompute", action="store_true", help="replay each Block in backward (activation ckpt)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="reduce-scatter gradients, AdamW on 1/N of every unit, all-gather the bf16 copies")
     return ap.parse_args()
 
 
@@ -141,7 +143,7 @@ def main():
     for blk in model.blocks:
         blk.recompute = a.recompute
     nparams = sum(p.numel() for p in model.parameters())
-    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential))
+    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential), shard_optimizer=a.shard_optimizer)
     opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
     scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0)
     loss_fn = Bayesian_TV(aggregate_only=True)

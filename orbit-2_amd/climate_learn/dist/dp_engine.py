@@ -13,6 +13,12 @@ As soon as every parameter of a unit has its gradient (the backward kernels call
 bucket is all-reduced on a dedicated HIP stream (RCCL over xGMI; `gloo` in CPU tests), ordered after the
 compute stream by an event, so communication overlaps the rest of backward.  The sum is divided by the
 world size inside the fused AdamW (grad_scale), as FSDP's NO_SHARD gradient averaging does.
+
+`shard_optimizer=True` (the SHARD_GRAD_OP-like step towards the reference's FULL/HYBRID sharding): every
+unit's bf16 bucket is REDUCE-SCATTERED instead of all-reduced, each rank runs AdamW on its 1/N chunk only (fp32 master
+chunk + both moments: optimizer state and update time shrink by N) and the updated bf16 compute copies are ALL-GATHERED
+back; same bytes on the wire as the all-reduce.  The fp32 masters of the other ranks' chunks are refreshed on demand
+(`consolidate_master`, called by `state_dict`).  The small fp32-compute parameters stay replicated.
 """
 from __future__ import annotations
 
@@ -52,6 +58,7 @@ class Bucket:
         self.name = name
         self.params: List[nn.Parameter] = []
         self.grad_views: List[torch.Tensor] = []   # contiguous ranges to all-reduce (bf16 and/or fp32)
+        self.lo_view: Optional[torch.Tensor] = None   # the bf16 range (reduce-scattered when the optimizer is sharded)
         self.pending = 0
         self.handle = None
         self.event = None
@@ -60,11 +67,13 @@ class Bucket:
 class HipDataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (),
                  is_lowp=None, sync_module_states: bool = True, overlap: bool = True,
-                 transposed_copies: bool = True):
+                 transposed_copies: bool = True, shard_optimizer: bool = False):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.shard = bool(shard_optimizer)
         # ORBIT2_FORCE_COLLECTIVES=1 issues the bucket all-reduces even on a single rank (exercises the RCCL path
         # -- streams, async handles, bf16 reduction -- on a 1-GPU box)
         import os as _os
@@ -84,10 +93,11 @@ class HipDataParallel(nn.Module):
             lo = [(n, p) for n, p in ps if is_lowp(n, p)]
             hi = [(n, p) for n, p in ps if not is_lowp(n, p)]
             plan.append((uname, lo, hi))
-            for _, p in ps:
-                n32 += _round_up(p.numel())
-            for _, p in lo:
-                n16 += _round_up(p.numel())
+            ulo = sum(_round_up(p.numel()) for _, p in lo)
+            if self.shard:
+                ulo = _round_up(ulo, self.world * _ALIGN)       # every rank's chunk of the unit stays aligned
+            n16 += ulo
+            n32 += ulo + sum(_round_up(p.numel()) for _, p in hi)
             for _, p in hi:
                 ng32 += _round_up(p.numel())
         self.flat32 = torch.zeros(n32, dtype=F32, device=dev)
@@ -100,6 +110,9 @@ class HipDataParallel(nn.Module):
         self.buckets: List[Bucket] = []
         self.lowp_ranges: List[Tuple[int, int, int]] = []   # (off32, off16, n) per unit
         self.hi_ranges: List[Tuple[int, int, int]] = []     # (off32, offg32, n) per unit
+        # what the optimizer touches on THIS rank: dicts(kind, o32, og, n, os); os = offset into the moment buffers
+        self.opt_segments: List[Dict] = []
+        self.opt_state_size = 0
         o32 = o16 = og32 = 0
         self._bucket_of: Dict[int, Bucket] = {}
         for uname, lo, hi in plan:
@@ -121,8 +134,21 @@ class HipDataParallel(nn.Module):
                 o32 += _round_up(k)
                 o16 += _round_up(k)
             if lo:
-                self.lowp_ranges.append((s32, s16, o16 - s16))
+                if self.shard:
+                    pad = _round_up(o16 - s16, self.world * _ALIGN) - (o16 - s16)
+                    o16 += pad
+                    o32 += pad
+                n_lo = o16 - s16
+                self.lowp_ranges.append((s32, s16, n_lo))
                 bk.grad_views.append(self.g16[s16:o16])
+                bk.lo_view = bk.grad_views[-1]
+                if self.shard:
+                    ck = n_lo // self.world
+                    self.opt_segments.append(dict(kind="lo", o32=s32 + self.rank * ck, og=s16 + self.rank * ck, n=ck,
+                                                  os=self.opt_state_size))
+                    self.opt_state_size += ck
+                else:
+                    self.opt_segments.append(dict(kind="lo", o32=s32, og=s16, n=n_lo, os=s32))
             s32h, sg = o32, og32
             for n, p in hi:
                 k = p.numel()
@@ -138,7 +164,14 @@ class HipDataParallel(nn.Module):
             if hi:
                 self.hi_ranges.append((s32h, sg, og32 - sg))
                 bk.grad_views.append(self.g32[sg:og32])
+                if self.shard:
+                    self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=self.opt_state_size))
+                    self.opt_state_size += og32 - sg
+                else:
+                    self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=s32h))
             self.buckets.append(bk)
+        if not self.shard:
+            self.opt_state_size = n32                      # moments laid out like flat32 (checkpoint format)
         self.refresh_compute_copies()
         if sync_module_states and (self.world > 1 or self.force_comm):
             dist.broadcast(self.flat32, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0,
@@ -190,6 +223,16 @@ class HipDataParallel(nn.Module):
         if bk.pending == 0:
             self._launch(bk)
 
+    def _reduce(self, bk: Bucket, v: torch.Tensor):
+        """all-reduce, or -- for the bf16 range of a sharded-optimizer engine -- reduce-scatter into this rank's
+        chunk of the same buffer (in place: output = input + rank*chunk, the form RCCL runs without a copy)"""
+        if self.shard and v is bk.lo_view and dist.get_backend(self.pg) == "nccl":
+            ck = v.numel() // self.world
+            return dist.reduce_scatter_tensor(v[self.rank * ck:(self.rank + 1) * ck], v, op=dist.ReduceOp.SUM,
+                                              group=self.pg, async_op=True)
+        # gloo (CPU tests) has no in-place reduce-scatter: the all-reduce leaves the same sum in this rank's chunk
+        return dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
     def _launch(self, bk: Bucket):
         self._launched.append(bk)
         if self.world == 1 and not self.force_comm:
@@ -199,11 +242,31 @@ class HipDataParallel(nn.Module):
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                bk.handle = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                             for v in bk.grad_views]
+                bk.handle = [self._reduce(bk, v) for v in bk.grad_views]
         else:
-            bk.handle = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                         for v in bk.grad_views]
+            bk.handle = [self._reduce(bk, v) for v in bk.grad_views]
+
+    def _gather_ranges(self, flat: torch.Tensor, which: int):
+        """all-gather every unit's low-precision range of `flat` (flat16: which = 1, flat32: which = 0) from the
+        ranks' chunks, in place"""
+        if self.world == 1 and not self.force_comm:
+            return
+        inplace = dist.get_backend(self.pg) == "nccl"
+        for rg in self.lowp_ranges:
+            off, n = rg[which], rg[2]
+            ck = n // self.world
+            mine = flat[off + self.rank * ck: off + (self.rank + 1) * ck]
+            dist.all_gather_into_tensor(flat[off:off + n], mine if inplace else mine.clone(), group=self.pg)
+
+    def gather_params(self):
+        """sharded optimizer: after the local AdamW, collect every rank's updated bf16 compute chunk"""
+        if self.shard:
+            self._gather_ranges(self.flat16, 1)
+
+    def consolidate_master(self):
+        """sharded optimizer: refresh the fp32 masters of the chunks other ranks own (checkpointing)"""
+        if self.shard:
+            self._gather_ranges(self.flat32, 0)
 
     def finish_grad_sync(self):
         """Block the compute stream until every launched all-reduce is done; reduce stragglers (units whose
@@ -228,6 +291,7 @@ class HipDataParallel(nn.Module):
         return self.module.data_config(*a, **k)
 
     def state_dict(self, *a, **k):
+        self.consolidate_master()
         return self.module.state_dict(*a, **k)
 
     def load_state_dict(self, sd, *a, **k):

@@ -27,8 +27,10 @@ class HipAdamW(torch.optim.Optimizer):
         self.found_inf = None
         self.grad_scale = 1.0
         if engine is not None:
-            self.m = torch.zeros_like(engine.flat32)
-            self.v = torch.zeros_like(engine.flat32)
+            # moments cover what this rank updates: everything (flat32 layout), or with a sharded optimizer its chunk
+            # of every unit's bf16 range plus the replicated fp32-compute parameters
+            self.m = torch.zeros(engine.opt_state_size, dtype=F32, device=engine.flat32.device)
+            self.v = torch.zeros(engine.opt_state_size, dtype=F32, device=engine.flat32.device)
             self.found_inf = torch.zeros(1, dtype=F32, device=engine.flat32.device)
 
     @torch.no_grad()
@@ -41,12 +43,15 @@ class HipAdamW(torch.optim.Optimizer):
             e.finish_grad_sync()
             gs = self.grad_scale / e.world
             fi = self.found_inf if self.check_inf else None
-            for o32, o16, n in e.lowp_ranges:
-                _hip.adamw(e.flat32[o32:], self.m[o32:], self.v[o32:], e.g16[o16:], e.flat16[o16:], n, lr, b1, b2, eps,
-                           wd, self._step, gs, fi)
-            for o32, og, n in e.hi_ranges:
-                _hip.adamw(e.flat32[o32:], self.m[o32:], self.v[o32:], e.g32[og:], None, n, lr, b1, b2, eps, wd,
-                           self._step, gs, fi)
+            for sg in e.opt_segments:
+                o32, og, n, os_ = sg["o32"], sg["og"], sg["n"], sg["os"]
+                if sg["kind"] == "lo":
+                    _hip.adamw(e.flat32[o32:], self.m[os_:], self.v[os_:], e.g16[og:], e.flat16[og:], n, lr, b1, b2, eps,
+                               wd, self._step, gs, fi)
+                else:
+                    _hip.adamw(e.flat32[o32:], self.m[os_:], self.v[os_:], e.g32[og:], None, n, lr, b1, b2, eps, wd,
+                               self._step, gs, fi)
+            e.gather_params()
             e.refresh_transposed_copies()
             return None
         # un-managed parameters (unit tests / tiny models): one launch per tensor
@@ -76,9 +81,28 @@ class HipAdamW(torch.optim.Optimizer):
         sd = super().state_dict()
         sd["orbit2"] = {"step": self._step}
         if self.engine is not None:
-            sd["orbit2"]["m"] = self.m
-            sd["orbit2"]["v"] = self.v
+            sd["orbit2"]["m"] = self._full_state(self.m)
+            sd["orbit2"]["v"] = self._full_state(self.v)
         return sd
+
+    def _full_state(self, st):
+        """moments in the flat32 layout (the checkpoint format of the unsharded engine)"""
+        e = self.engine
+        if not e.shard:
+            return st
+        full = torch.zeros_like(e.flat32)
+        for sg in e.opt_segments:
+            full[sg["o32"]:sg["o32"] + sg["n"]].copy_(st[sg["os"]:sg["os"] + sg["n"]])
+        e._gather_ranges(full, 0)
+        return full
+
+    def _load_full_state(self, st, full):
+        e = self.engine
+        if not e.shard:
+            st.copy_(full)
+            return
+        for sg in e.opt_segments:
+            st[sg["os"]:sg["os"] + sg["n"]].copy_(full[sg["o32"]:sg["o32"] + sg["n"]])
 
     def load_state_dict(self, sd):
         extra = sd.pop("orbit2", None)
@@ -86,8 +110,8 @@ class HipAdamW(torch.optim.Optimizer):
         if extra:
             self._step = extra["step"]
             if self.engine is not None and "m" in extra:
-                self.m.copy_(extra["m"])
-                self.v.copy_(extra["v"])
+                self._load_full_state(self.m, extra["m"].to(self.m.device))
+                self._load_full_state(self.v, extra["v"].to(self.v.device))
 
 
 class HipGradScaler:
@@ -114,10 +138,8 @@ class HipGradScaler:
         eng.finish_grad_sync()
         fi = optimizer.found_inf
         fi.zero_()
-        for _, o16, n in eng.lowp_ranges:
-            _hip.check_finite(eng.g16[o16:], n, fi)
-        for _, og, n in eng.hi_ranges:
-            _hip.check_finite(eng.g32[og:], n, fi)
+        for sg in eng.opt_segments:       # with a sharded optimizer: this rank's reduced chunk of every bf16 bucket
+            _hip.check_finite((eng.g16 if sg["kind"] == "lo" else eng.g32)[sg["og"]:], sg["n"], fi)
         if eng.world > 1:
             dist.all_reduce(fi, op=dist.ReduceOp.MAX, group=eng.pg)
         optimizer.grad_scale = 1.0 / self._scale

@@ -95,6 +95,86 @@ def test_engine_world2_gloo():
     assert all(r[1] == "ok" for r in res), res
 
 
+def _worker_sharded(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import climate_learn as cl
+        from climate_learn.models.hub.components.vit_blocks import Block
+        torch.manual_seed(7)
+        model = _build()
+        n_param = sum(p.numel() for p in model.parameters())
+        eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential), overlap=False, shard_optimizer=True)
+        # layout: every unit's bf16 range splits into `world` aligned chunks; the optimizer owns one chunk per unit
+        lo_total = 0
+        for (o32, o16, n) in eng.lowp_ranges:
+            assert n % (world * 128) == 0
+            lo_total += n
+        segs = eng.opt_segments
+        assert sum(s["n"] for s in segs if s["kind"] == "lo") == lo_total // world
+        assert eng.opt_state_size == lo_total // world + sum(r[2] for r in eng.hi_ranges) < n_param
+        # parameters are still views of the flat buffers with their own shapes
+        w = model.blocks[1].mlp.fc1.weight
+        assert w._o2g.shape == w.shape and w._o2c.shape == w.shape
+        # simulated backward with rank-dependent gradients
+        eng.zero_grad()
+        for bk in reversed(eng.buckets):
+            for p in bk.params:
+                if hasattr(p, "_o2g"):
+                    p._o2g.fill_(float(rank + 1))
+                    p._o2_fresh = False
+                    eng.grad_ready(p)
+                else:
+                    p.grad.add_(float(rank + 1) * 0.25)
+                    eng._hi_hook(p)
+        eng.finish_grad_sync()
+        tot = float(sum(range(1, world + 1)))
+        for sg in segs:        # the reduced gradient is valid at least on the chunk this rank updates
+            g = (eng.g16 if sg["kind"] == "lo" else eng.g32)[sg["og"]:sg["og"] + sg["n"]].float()
+            used = g[g != 0]
+            assert used.numel() > 0 and torch.all((used == tot) | (used == 0.25 * tot))
+        # stand-in optimizer step: every rank rewrites only its own chunks, then the engine gathers
+        for sg in segs:
+            if sg["kind"] == "lo":
+                eng.flat32[sg["o32"]:sg["o32"] + sg["n"]] = float(10 + rank)
+                eng.flat16[sg["og"]:sg["og"] + sg["n"]] = float(10 + rank)
+        eng.gather_params()
+        for (o32, o16, n) in eng.lowp_ranges:
+            ck = n // world
+            for r in range(world):
+                assert torch.all(eng.flat16[o16 + r * ck:o16 + (r + 1) * ck].float() == 10 + r)
+        sd = eng.state_dict()                                     # consolidates the fp32 masters
+        for (o32, o16, n) in eng.lowp_ranges:
+            ck = n // world
+            for r in range(world):
+                assert torch.all(eng.flat32[o32 + r * ck:o32 + (r + 1) * ck] == 10 + r)
+        both = [torch.zeros_like(eng.flat32) for _ in range(world)]
+        dist.all_gather(both, eng.flat32)
+        assert torch.equal(both[0], both[1]) and all(v.dtype == torch.float32 for v in sd.values())
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_engine_sharded_optimizer_world2_gloo():
+    """reduce-scatter / all-gather data path of the sharded-optimizer mode on two gloo ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def test_engine_single_process_layout():
     import climate_learn as cl
     from climate_learn.models.hub.components.vit_blocks import Block

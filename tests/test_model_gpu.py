@@ -114,6 +114,65 @@ def test_engine_adamw_trajectory_vs_reference_golden(golden_dir, tag):
     assert torch.equal(w._o2c.float(), w.data.to(torch.bfloat16).float())
 
 
+def test_sharded_optimizer_matches_replicated_engine(golden_dir, monkeypatch):
+    """shard_optimizer=True on a single-rank RCCL group with the collectives forced on (the in-place reduce-scatter and
+    all-gather really run).  Fed the same gradient buffers, the sharded engine's scaler + AdamW step leaves parameters,
+    bf16 compute copies and (gathered) moments bit-identical to the all-reduce engine's, over three steps; a
+    checkpoint written by one mode loads in the other.  (Whole-step comparisons are not bitwise: the var-agg backward
+    accumulates with fp32 atomics and AdamW amplifies ~1-ulp gradient differences of near-zero gradients.)"""
+    import torch.distributed as dist
+    import climate_learn as cl
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29655")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        eng, opt, scl = {}, {}, {}
+        for mode in (False, True):
+            c, z, sd, m = load(golden_dir, "v5c1_hd64")
+            eng[mode] = cl.HipDataParallel(m, unit_types=(Block, nn.Sequential), shard_optimizer=mode)
+            assert eng[mode].force_comm and eng[mode].shard == mode
+            opt[mode] = cl.load_optimizer(eng[mode], "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+            scl[mode] = cl.HipGradScaler(init_scale=1024.0)
+        a, b = eng[False], eng[True]
+        assert a.flat32.shape == b.flat32.shape and torch.equal(a.flat32, b.flat32)       # world 1: same layout
+        x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+        for step in range(3):
+            loss = training_step((x, y, c["in_vars"], c["out_vars"]), step, a, torch.device("cuda"), VW,
+                                 Bayesian_TV(aggregate_only=True))
+            opt[False].zero_grad()
+            opt[True].zero_grad()
+            scl[False].scale(loss).backward()
+            a.finish_grad_sync()
+            b.g16.copy_(a.g16)                      # hand the sharded engine the very same gradients ...
+            b.g32.copy_(a.g32)
+            for bk in b.buckets:                    # ... and let it run its own reduce-scatter on them
+                b._launch(bk)
+            scl[False].step(opt[False])
+            scl[False].update()
+            scl[True].step(opt[True])
+            scl[True].update()
+            assert torch.equal(a.flat32, b.flat32) and torch.equal(a.flat16, b.flat16), step
+        sa, sb = opt[False].state_dict()["orbit2"], opt[True].state_dict()["orbit2"]
+        assert sa["step"] == sb["step"] == 3 and torch.equal(sa["m"], sb["m"]) and torch.equal(sa["v"], sb["v"])
+        assert float(sa["m"].abs().sum()) > 0
+        w = b.module.head[0].weight
+        assert torch.equal(w._o2ct, w._o2c.t().contiguous())            # transposed copies follow the gathered copies
+        # cross-mode resume
+        opt[True].load_state_dict(opt[False].state_dict())
+        assert torch.equal(opt[True].state_dict()["orbit2"]["m"], sa["m"])
+        pa, pb = a.state_dict(), b.state_dict()
+        assert all(torch.equal(pa[k], pb[k]) for k in pa)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_train_mode_dropout_and_recompute_match():
     """recompute (activation-checkpoint counterpart) replays the same dropout masks: identical gradients."""
     from climate_learn import manual_seed
