@@ -1,0 +1,187 @@
+"""Parity at the BASELINE configuration's FULL sizes (interm_1b: B x 8192 tokens x 3072 channels, 24 heads of 128),
+where the CPU oracle cannot run the whole problem: each kernel is checked (a) on a random SAMPLE of its outputs
+against an fp64 restatement that needs only the inputs of those outputs, and (b) through size-independent properties
+(rows of softmax sum to one, gradient column-sum identities, linearity, batch independence, determinism)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orbit2_oracle as O
+from tests.hashmask import keep_mask
+
+BF = torch.bfloat16
+B_, L_, D_, H_, HID_ = 2, 8192, 3072, 24, 12288
+M_ = B_ * L_
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from climate_learn import _hip
+    _hip.lib()
+    return _hip
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device="cuda") * scale).to(BF)
+
+
+def test_gemm_forward_and_dw_forms_sampled_entries(hip):
+    """fc1 forward (ring kernel, bias + GELU + dropout epilogue) and the four grouped dW GEMMs at the 1b shapes:
+    4096 random output entries each against fp64 dot products of the very same bf16 inputs"""
+    x, w1, b1 = rnd(M_, D_, seed=1), rnd(HID_, D_, scale=0.03, seed=2), rnd(HID_, seed=3)
+    out = torch.empty(M_, HID_, dtype=BF, device="cuda")
+    pre = torch.empty(M_, HID_, dtype=BF, device="cuda")
+    p, seed = 0.1, 424242
+    hip.gemm(x, w1, out, M_, HID_, D_, D_, D_, HID_, bias=b1, act=1, save_pre=pre, drop_p=p, seed=seed)
+    g = torch.Generator().manual_seed(5)
+    mi = torch.randint(0, M_, (4096,), generator=g).cuda()
+    ni = torch.randint(0, HID_, (4096,), generator=g).cuda()
+    ref_pre = (x[mi].double() * w1[ni].double()).sum(1) + b1[ni].double()
+    assert float((pre[mi, ni].double() - ref_pre).abs().max() / ref_pre.abs().max()) < 6e-3
+    # dropout mask of element (m, n): byte ((m*N+n) & 3) of hash((m*N+n) >> 2); evaluate the replica only on the sample
+    from tests.hashmask import o2_hash64
+    idx = (mi.cpu().numpy().astype(np.uint64) * np.uint64(HID_) + ni.cpu().numpy().astype(np.uint64))
+    hh = o2_hash64(seed, idx >> np.uint64(2))
+    keep = ((hh >> ((idx & np.uint64(3)) * np.uint64(8))) & np.uint64(0xFF)) >= np.uint64(26)
+    ref_out = F.gelu(pre[mi, ni].double().cpu()) * torch.from_numpy(keep.astype(np.float64)) * (256.0 / 230.0)
+    assert float((out[mi, ni].double().cpu() - ref_out).abs().max() / ref_out.abs().max()) < 8e-3
+    # grouped weight-gradient GEMMs: dW[n_out, n_in] = sum_t dY[t, n_out] X[t, n_in]
+    probs, chk = [], []
+    for i, (no, ni_) in enumerate(((3 * D_, D_), (D_, D_), (HID_, D_), (D_, HID_))):
+        dy, xx = rnd(M_, no, scale=0.05, seed=10 + i), rnd(M_, ni_, seed=20 + i)
+        dw = torch.empty(no, ni_, dtype=BF, device="cuda")
+        probs.append((dy, xx, dw, no, ni_, M_, no, ni_, ni_, dict(a_kc=False, b_kc=False)))
+        chk.append((dy, xx, dw, no, ni_))
+    hip.gemm_grouped(probs)
+    for dy, xx, dw, no, ni_ in chk:
+        a = torch.randint(0, no, (512,), generator=g).cuda()
+        b = torch.randint(0, ni_, (512,), generator=g).cuda()
+        ref = (dy[:, a].double() * xx[:, b].double()).sum(0)
+        assert float((dw[a, b].double() - ref).abs().max() / ref.abs().max()) < 6e-3
+
+
+def test_attention_full_length_rows_and_identities(hip):
+    """L = 8192, 24 heads of 128: sampled query rows of out / lse / dQ against an fp64 row-wise restatement, plus the
+    identities sum_k dV[k] = sum_q dO[q] (rows of P sum to one) and sum_k dK[k] = 0 when all queries are equal"""
+    B, L, H, d = 1, L_, H_, 128
+    qkv = rnd(B, L, 3 * H * d, scale=0.7, seed=31)
+    do = rnd(B, L, H * d, seed=32)
+    out, lse = hip.attn_fwd(qkv, B, L, H, d, 0.0, 0)
+    dqkv = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, 0.0, 0)
+    q5 = qkv.view(B, L, 3, H, d)
+    g = torch.Generator().manual_seed(7)
+    for _ in range(24):
+        h, q = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, L, (1,), generator=g))
+        qv, K, V = q5[0, q, 0, h].double(), q5[0, :, 1, h].double(), q5[0, :, 2, h].double()
+        s = (K @ qv) * d ** -0.5
+        pr = torch.softmax(s, 0)
+        o_ref = pr @ V
+        assert float((out.view(B, L, H, d)[0, q, h].double() - o_ref).abs().max() / o_ref.abs().max()) < 1.5e-2
+        assert abs(float(lse[0, h, q]) - float(torch.logsumexp(s, 0))) < 2e-3
+        dov = do.view(B, L, H, d)[0, q, h].double()
+        dp = V @ dov
+        ds = pr * (dp - (pr * dp).sum())
+        dq_ref = (ds @ K) * d ** -0.5
+        got = dqkv.view(B, L, 3, H, d)[0, q, 0, h].double()
+        assert float((got - dq_ref).abs().max() / dq_ref.abs().max()) < 3e-2
+    dv_sum = dqkv.view(B, L, 3, H, d)[0, :, 2].double().sum(0)              # [H, d]
+    do_sum = do.view(B, L, H, d)[0].double().sum(0)
+    assert float((dv_sum - do_sum).abs().max() / do_sum.abs().max()) < 2e-2
+    # all queries equal -> every row of dS sums to zero and dK[k] = scale * q * sum_q dS[q, k] sums to zero over k
+    qkv2 = qkv.clone()
+    qkv2.view(B, L, 3, H, d)[:, :, 0] = qkv2.view(B, L, 3, H, d)[:, :1, 0]
+    out2, lse2 = hip.attn_fwd(qkv2, B, L, H, d, 0.0, 0)
+    dq2 = hip.attn_bwd(qkv2, out2, do, lse2, B, L, H, d, 0.0, 0).view(B, L, 3, H, d)
+    dk = dq2[0, :, 1].double()
+    assert float(dk.sum(0).abs().max() / dk.abs().sum(0).max()) < 2e-3
+    # dropout on: same seed -> bit-identical, another seed -> another mask, E[out] preserved to the dropout noise level
+    o1, _ = hip.attn_fwd(qkv, B, L, H, d, 0.1, 77)
+    o2, _ = hip.attn_fwd(qkv, B, L, H, d, 0.1, 77)
+    o3, _ = hip.attn_fwd(qkv, B, L, H, d, 0.1, 78)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    assert float((o1.double() - out.double()).mean().abs()) < 1e-3
+
+
+def test_layernorm_adamw_sampled(hip):
+    x = rnd(M_, D_, scale=2.0, seed=41)
+    gam, bet = rnd(D_, seed=42), rnd(D_, seed=43)
+    y, mean, rstd = hip.layernorm_fwd(x, gam, bet)
+    g = torch.Generator().manual_seed(9)
+    rows = torch.randint(0, M_, (256,), generator=g).cuda()
+    ref = F.layer_norm(x[rows].double(), (D_,), gam.double(), bet.double(), 1e-5)
+    assert float((y[rows].double() - ref).abs().max() / ref.abs().max()) < 6e-3
+    # fused AdamW over 2^28 elements, 3 steps, sampled against the oracle's formula
+    n = 1 << 28
+    gg = torch.Generator(device="cuda").manual_seed(44)
+    p = torch.randn(n, generator=gg, device="cuda")
+    grad = (torch.randn(n, generator=gg, device="cuda") * 3e-3).to(BF)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    p16 = torch.empty(n, dtype=BF, device="cuda")
+    idx = torch.randint(0, n, (4096,), generator=g).cuda()
+    pr, mr, vr = p[idx].double().cpu(), torch.zeros(4096, dtype=torch.float64), torch.zeros(4096, dtype=torch.float64)
+    gr = grad[idx].double().cpu() * 0.5
+    for step in (1, 2, 3):
+        hip.adamw(p, m, v, grad, p16, n, 5e-4, 0.9, 0.99, 1e-8, 1e-5, step, 0.5, None)
+        O.adamw_step(pr, gr, mr, vr, step, 5e-4, 0.9, 0.99, 1e-8, 1e-5)       # in place on (p, m, v)
+    assert float((p[idx].double().cpu() - pr).abs().max()) < 2e-6
+    assert torch.equal(p16[idx].float(), p[idx].to(BF).float())
+
+
+def test_varagg_full_grid_sampled_tokens_and_linearity(hip):
+    """V = 23 variables on the 128 x 256 grid (8192 tokens / sample), D = 3072, 24 heads: sampled tokens of the folded
+    forward against the table algebra in fp64, and linearity of the MFMA backward in dz"""
+    V, h, w = 23, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(51)
+    x = torch.randn(B_, V, h, w, generator=g, device="cuda")
+    stab = torch.randn(H_, V, 5, generator=g, device="cuda") * 0.4
+    gtab = torch.randn(V, 5, D_, generator=g, device="cuda") * 0.1
+    z, attw = hip.varagg_fwd(x, stab, gtab, H_, D_)
+    gc = torch.Generator().manual_seed(3)
+    dh = D_ // H_
+    for _ in range(16):
+        tok = int(torch.randint(0, M_, (1,), generator=gc))
+        b, l = divmod(tok, L_)
+        pr_, pc = divmod(l, w // 2)
+        pt = torch.ones(V, 5, dtype=torch.float64)
+        pt[:, :4] = x[b, :, 2 * pr_:2 * pr_ + 2, 2 * pc:2 * pc + 2].reshape(V, 4).double().cpu()
+        a = torch.softmax((stab.double().cpu() * pt).sum(-1), -1)                       # [H, V]
+        val = (gtab.double().cpu() * pt[:, :, None]).sum(1)                             # [V, D]
+        ref = torch.cat([(a[hh, :, None] * val[:, hh * dh:(hh + 1) * dh]).sum(0) for hh in range(H_)])
+        assert float((z[tok].double().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3
+        assert float((attw[tok].double().cpu() - a).abs().max()) < 1e-5
+    dz1, dz2 = rnd(M_, D_, seed=52), rnd(M_, D_, seed=53)
+    s1, g1 = hip.varagg_bwd(x, gtab, attw, dz1, H_, D_)
+    s2, g2 = hip.varagg_bwd(x, gtab, attw, dz2, H_, D_)
+    s12, g12 = hip.varagg_bwd(x, gtab, attw, (dz1.float() * 0.5 + dz2.float() * 0.25).to(BF), H_, D_)
+    # dz1/2 + dz2/4 is rounded to bf16 once more: linear up to that rounding (2^-9 relative per element, averaged)
+    assert float((g12 - (0.5 * g1 + 0.25 * g2)).abs().max() / g12.abs().max()) < 2e-3
+    assert float((s12 - (0.5 * s1 + 0.25 * s2)).abs().max() / s12.abs().max()) < 2e-3
+
+
+def test_interm_1b_model_batch_independence_and_determinism():
+    """the whole interm_1b network at its real size (1.0 B parameters, 128 x 256 grid): eval-mode predictions of a
+    sample do not depend on its batch neighbours, and a repeated forward is bit-identical"""
+    from climate_learn.models.hub import Res_Slim_ViT
+    consts = ["land_sea_mask", "orography", "lattitude", "landcover"]
+    dv = consts + ["v%d" % i for i in range(18)] + ["total_precipitation_24hr"]
+    outs = ["total_precipitation_24hr", "v0", "v1"]
+    with torch.device("cuda"):
+        m = Res_Slim_ViT(dv, (128, 256), len(dv), 3, 4, patch_size=2, embed_dim=3072, depth=8, decoder_depth=4,
+                         num_heads=24, drop_path=0.1, drop_rate=0.1)
+    m = m.cuda().eval()
+    assert 0.99e9 < sum(p.numel() for p in m.parameters()) < 1.02e9
+    g = torch.Generator(device="cuda").manual_seed(61)
+    x = torch.randn(2, len(dv), 128, 256, generator=g, device="cuda")
+    with torch.no_grad():
+        y2 = m(x, dv, outs)
+        y2b = m(x, dv, outs)
+        y1 = m(x[1:2].contiguous(), dv, outs)
+    assert y2.shape == (2, 3, 512, 1024) and torch.isfinite(y2).all()
+    assert torch.equal(y2, y2b)
+    assert torch.equal(y2[1:2], y1)
