@@ -188,6 +188,12 @@ int orbit2_adamw(float* p, float* m, float* v, const void* g, int g_fp32, void* 
 /* found_inf[0] = 1 if any element is inf/nan (never cleared here) */
 int orbit2_check_finite(const void* g, int g_fp32, int64_t n, float* found_inf, void* stream);
 
+/* Device-side seed salt: every seeded kernel (GEMM-epilogue dropout, attention dropout, dropout backward, DropPath
+ * scales) xors it into the seed argument.  add = 0 sets it, add = 1 advances it by `value`; stream-ordered (a one-thread
+ * kernel per library module).  0 by default, i.e. the seeds are used as passed.  Purpose: a training step captured in a
+ * hipGraph begins with orbit2_seed_salt(odd constant, 1, stream), so each replay draws new masks. */
+int orbit2_seed_salt(uint64_t value, int add, void* stream);
+
 /* hardware self-test of the MFMA / LDS-transpose / LDS-DMA layouts the kernels assume; returns a
  * bitmask of failed checks in result[0] (0 = all good). */
 int orbit2_selftest(int* result, void* stream);

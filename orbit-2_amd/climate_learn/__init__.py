@@ -19,3 +19,4 @@ from . import data
 from .dist.dp_engine import HipDataParallel
 from .optim import HipAdamW, HipGradScaler
 from ._ops import manual_seed
+from .graphs import GraphedTrainStep

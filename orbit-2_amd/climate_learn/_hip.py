@@ -488,3 +488,8 @@ def eval_moments(pred, target, lat_w=None):
     _chk(lib().orbit2_eval_moments(_p(pred), _p(target), target.shape[2], target.shape[3], _p(lat_w), _p(out), B, Cc, H,
                                    W, _stream()), "orbit2_eval_moments")
     return out
+
+
+def seed_salt(value: int, add: bool = False):
+    """device-side salt xored into every kernel seed (see include/orbit2_hip.h:orbit2_seed_salt); stream-ordered"""
+    _chk(lib().orbit2_seed_salt(C.c_uint64(value & 0xFFFFFFFFFFFFFFFF), int(add), _stream()), "orbit2_seed_salt")

@@ -35,6 +35,13 @@ class _SeedStream:
         self.base = (int(seed) * 0x9E3779B97F4A7C15 + (rank + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self.counter = 0
 
+    def mark(self) -> int:
+        """position of the stream (GraphedTrainStep rewinds to it so warm-up and capture issue the same seeds)"""
+        return self.counter
+
+    def reset(self, mark: int):
+        self.counter = mark
+
     def next(self) -> int:
         self.counter += 1
         z = (self.base + self.counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF

@@ -1,0 +1,72 @@
+"""hipGraph capture of the launch-bound part of a training step.
+
+The small configurations (interm_8m / interm_117m on 32 x 64 grids) issue ~1000 kernels of a few microseconds per step:
+the GPU waits for the Python launch loop.  `GraphedTrainStep` records zero_grad + forward + loss + (scaled) backward once
+into a hipGraph (`torch.cuda.CUDAGraph`) and replays it with a single launch; the optimizer / loss-scaler step stays
+eager (its arguments -- learning rate, bias corrections, found_inf handling -- change every step).
+
+Dropout / DropPath seeds are kernel ARGUMENTS, frozen at capture.  The captured sequence therefore begins with
+`orbit2_seed_salt(odd constant, add)`: a one-thread kernel that advances a device-side salt every seeded kernel xors into
+its seed, so each replay draws new masks while forward and backward of one replay still agree.
+
+Single-rank engines only for now: with more ranks the bucket all-reduces would have to be captured together with the
+comm-stream events (RCCL supports capture; the engine's bookkeeping of async handles does not yet)."""
+from typing import Optional
+
+import torch
+
+from . import _hip
+from .trainer import training_step
+
+SALT_STEP = 0x9E3779B97F4A7C15       # odd: the salt walks through all 2^64 values
+
+
+class GraphedTrainStep:
+    def __init__(self, engine, loss_metric, batch, var_weights, scaler=None, warmup: int = 2):
+        if getattr(engine, "world", 1) != 1:
+            raise NotImplementedError("GraphedTrainStep supports single-rank engines (see module docstring)")
+        x, y, self.in_vars, self.out_vars = batch
+        self.engine, self.loss_metric, self.var_weights, self.scaler = engine, loss_metric, var_weights, scaler
+        self.device = engine.device
+        self.x = x.to(self.device).clone()           # static input buffers: refill with .copy_ between replays
+        self.y = y.to(self.device).clone()
+        self.warmup = warmup
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.loss: Optional[torch.Tensor] = None
+        self.scale = 1.0
+        self.captures = 0
+
+    def _body(self):
+        from . import _ops
+        _hip.seed_salt(SALT_STEP, add=True)
+        _ops.seeds.reset(self._seed_mark)            # the same per-launch seeds at capture time and in the warm-ups
+        self.engine.zero_grad()
+        loss = training_step((self.x, self.y, self.in_vars, self.out_vars), 0, self.engine, self.device,
+                             self.var_weights, self.loss_metric)
+        (loss * self.scale).backward()
+        return loss.detach()
+
+    def capture(self):
+        from . import _ops
+        self.scale = float(self.scaler.get_scale()) if self.scaler is not None else 1.0
+        self._seed_mark = _ops.seeds.mark()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # allocator warm-up and lazy one-time initialisations, uncaptured
+            for _ in range(self.warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        self.captures += 1
+
+    def __call__(self, batch=None):
+        """runs one step's zero_grad + forward + loss + backward; returns the (static) loss tensor"""
+        if batch is not None:
+            self.x.copy_(batch[0], non_blocking=True)
+            self.y.copy_(batch[1], non_blocking=True)
+        if self.graph is None or (self.scaler is not None and float(self.scaler.get_scale()) != self.scale):
+            self.capture()                           # first use, or the loss scale (a captured constant) moved
+        self.graph.replay()
+        return self.loss

@@ -9,12 +9,19 @@ import torch
 from .. import _ops
 
 
+_CW_CACHE = {}
+
+
 def _chan_weights(pred, var_names, var_weights):
     if var_names is None:
         return None
     assert len(var_names) == pred.shape[1], "Number of variable names must match channel dimension"
-    w = [float((var_weights or {}).get(v, 1.0)) for v in var_names]
-    return torch.tensor(w, dtype=torch.float32, device=pred.device)
+    w = tuple(float((var_weights or {}).get(v, 1.0)) for v in var_names)
+    key = (w, str(pred.device))
+    t = _CW_CACHE.get(key)       # cached: no host-to-device copy inside a step (a captured hipGraph forbids one)
+    if t is None:
+        t = _CW_CACHE[key] = torch.tensor(w, dtype=torch.float32, device=pred.device)
+    return t
 
 
 def _lat(lat_weights, pred):

@@ -65,7 +65,8 @@ __device__ __forceinline__ void stage_keyhash(uint32_t* skh, uint64_t seed, int 
 template <int D, bool DROP, bool RAGGED>
 __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
-                                                          unsigned thr, float dscale, uint64_t seed) {
+                                                          unsigned thr, float dscale, uint64_t seed_arg) {
+  const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // [2 stages][K | V]
   __shared__ __attribute__((aligned(16))) uint32_t skh[2][16];      // [stage] key-group hashes of the tile (dropout)
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                             unsigned thr, float dscale, uint64_t seed) {
+                                                             unsigned thr, float dscale, uint64_t seed_arg) {
+  const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];
   __shared__ __attribute__((aligned(16))) uint32_t skh[2][16];
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                              unsigned thr, float dscale, uint64_t seed) {
+                                                              unsigned thr, float dscale, uint64_t seed_arg) {
+  const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   constexpr bool DO_DK = WHICH != 2, DO_DV = WHICH != 1;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE + 2 * 3 * 64 * 4];  // [2][Q|dO] + [2][lse2|delta|row hash]
@@ -532,6 +535,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 }
 
 }  // namespace
+
+O2_DEFINE_SALT_OP(attn)
 
 static int attn_check(const void* a, const void* b, int B, int L, int H, int d, float p) {
   if (!a || !b || B <= 0 || L <= 0 || H <= 0) return O2_ERR_ARG;

@@ -36,6 +36,24 @@ __device__ __forceinline__ bf16x4 lds_tr4(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, lds_addr));
 }
 
+// ---- device-side seed salt --------------------------------------------------------------
+// Every seeded kernel xors this word into the seed it was launched with.  It is 0 unless a caller bumps it
+// (orbit2_seed_salt): a training step captured in a hipGraph has its kernel arguments -- the seeds -- frozen, so the graph
+// starts with a one-thread kernel that advances the salt and every replay draws fresh dropout / DropPath masks while
+// forward and backward of the same replay still agree.  One copy per translation unit (no relocatable device code);
+// orbit2_seed_salt updates all of them.
+static __device__ uint64_t o2_seed_salt = 0;
+#define O2_DEFINE_SALT_OP(tag)                                                                           \
+  namespace {                                                                                            \
+  __global__ void o2_salt_kernel_##tag(uint64_t v, int add) { o2_seed_salt = add ? o2_seed_salt + v : v; } \
+  }                                                                                                      \
+  void o2_salt_op_##tag(uint64_t v, int add, hipStream_t s) {                                            \
+    hipLaunchKernelGGL(o2_salt_kernel_##tag, dim3(1), dim3(1), 0, s, v, add);                            \
+  }
+void o2_salt_op_gemm(uint64_t v, int add, hipStream_t s);
+void o2_salt_op_attn(uint64_t v, int add, hipStream_t s);
+void o2_salt_op_elem(uint64_t v, int add, hipStream_t s);
+
 // ---- counter-based dropout hash ------------------------------------------------------
 // One 32-bit hash per group of 4 consecutive elements; element e of the group uses byte e.
 // keep <=> byte >= thr   (thr = round(p*256), effective drop prob thr/256, scale 256/(256-thr)).

@@ -115,7 +115,7 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
   }
   if (e.thr) {
     const uint64_t idx = ((uint64_t)m * (uint64_t)e.N + (uint64_t)n) >> 2;
-    const uint32_t h = o2_hash64(e.seed, idx);
+    const uint32_t h = o2_hash64(e.seed ^ o2_seed_salt, idx);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = (((h >> (8 * j)) & 0xffu) >= e.thr) ? v[j] * e.dscale : 0.f;
   }
@@ -212,7 +212,7 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
     const uint64_t idx = ((uint64_t)m * (uint64_t)e.N + (uint64_t)n) >> 2;
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
-      const uint32_t h = o2_hash64(e.seed, idx + hlf);
+      const uint32_t h = o2_hash64(e.seed ^ o2_seed_salt, idx + hlf);
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * hlf + j] = (((h >> (8 * j)) & 0xffu) >= e.thr) ? v[4 * hlf + j] * e.dscale : 0.f;
     }
@@ -614,6 +614,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 }
 
 }  // namespace
+
+O2_DEFINE_SALT_OP(gemm)
 
 extern "C" int orbit2_abi_version(void) { return ORBIT2_ABI_VERSION; }
 

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f((bf16_t)(v[j] & 0xffff)); f[2 * j + 1] = bf2f((bf16_t)(v[j] >> 16)); }
     if (thr) {
-      const uint32_t h0 = o2_hash64(seed, (uint64_t)idx >> 2), h1 = o2_hash64(seed, ((uint64_t)idx >> 2) + 1);
+      const uint64_t sd = seed ^ o2_seed_salt;
+      const uint32_t h0 = o2_hash64(sd, (uint64_t)idx >> 2), h1 = o2_hash64(sd, ((uint64_t)idx >> 2) + 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f[j] = (((h0 >> (8 * j)) & 0xffu) >= thr) ? f[j] * dscale : 0.f;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const void* __restric
 __global__ void droppath_scales_kernel(float* __restrict__ out, int B, float p, uint64_t seed) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const uint32_t h = o2_hash64(seed ^ 0xD1B54A32D192ED03ull, (uint64_t)b);
+  const uint32_t h = o2_hash64(seed ^ o2_seed_salt ^ 0xD1B54A32D192ED03ull, (uint64_t)b);
   const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
   out[b] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
 }
@@ -546,6 +547,17 @@ extern "C" int orbit2_check_finite(const void* g, int g_fp32, int64_t n, float* 
   dim3 grid(grid_for(n, 256 * 8)), block(256);
   if (g_fp32) hipLaunchKernelGGL(check_finite_kernel<true>, grid, block, 0, (hipStream_t)stream, g, n, found_inf);
   else hipLaunchKernelGGL(check_finite_kernel<false>, grid, block, 0, (hipStream_t)stream, g, n, found_inf);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+O2_DEFINE_SALT_OP(elem)
+
+extern "C" int orbit2_seed_salt(uint64_t value, int add, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  o2_salt_op_gemm(value, add, s);
+  o2_salt_op_attn(value, add, s);
+  o2_salt_op_elem(value, add, s);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

@@ -173,6 +173,68 @@ def test_sharded_optimizer_matches_replicated_engine(golden_dir, monkeypatch):
             dist.destroy_process_group()
 
 
+def test_graphed_step_matches_eager_and_draws_new_masks():
+    """zero_grad + forward + loss + backward captured in a hipGraph: the first replay reproduces the eager step that
+    uses the same seeds and the same device-side salt (loss and every gradient bucket bit for bit, except the var-agg
+    tables' atomically accumulated gradients), later replays draw other dropout masks, and training through the graph
+    + eager scaler/AdamW still descends"""
+    import climate_learn as cl
+    from climate_learn import _hip, _ops
+    from climate_learn.graphs import GraphedTrainStep, SALT_STEP
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.testing import build_pair
+    from climate_learn.trainer import training_step
+
+    def fresh():
+        model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2, grid=(16, 32), B=2, seed=21)
+        for blk in model.blocks:                     # train-mode dropout everywhere
+            blk.attn.attn_drop_p = blk.attn.proj_drop_p = blk.mlp.drop = 0.1
+            blk.drop_path = 0.1
+        model.pos_drop_p = 0.1
+        model = model.cuda().train()
+        eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential))
+        return eng, (x, y, in_vars, out_vars)
+
+    vw = {"total_precipitation_24hr": 1.0}
+    loss_fn = Bayesian_TV(aggregate_only=True)
+    try:
+        # eager reference with the salt the first replay will see (warm-ups: 2 bumps, capture: none executes, replay: 1)
+        eng_e, batch = fresh()
+        cl.manual_seed(5)
+        mark = _ops.seeds.mark()
+        _hip.seed_salt(3 * SALT_STEP, add=False)
+        eng_e.zero_grad()
+        le = training_step(batch, 0, eng_e, torch.device("cuda"), vw, loss_fn)
+        (le * 64.0).backward()
+        g_e = eng_e.g16.clone()
+        # graphed
+        eng_g, batch = fresh()
+        cl.manual_seed(5)
+        assert _ops.seeds.mark() == mark
+        _hip.seed_salt(0, add=False)
+        scaler = cl.HipGradScaler(init_scale=64.0, growth_interval=1000)
+        step = GraphedTrainStep(eng_g, loss_fn, batch, vw, scaler=scaler)
+        l1 = step().clone()
+        g1 = eng_g.g16.clone()
+        assert float(l1) == float(le)
+        assert torch.equal(g1, g_e)
+        l2 = step().clone()
+        g2 = eng_g.g16.clone()
+        assert float(l2) != float(l1) and not torch.equal(g2, g1)          # new masks, same weights
+        assert abs(float(l2) - float(l1)) / float(l1) < 0.2
+        # train through the graph: eager scaler + fused AdamW between replays
+        opt = cl.load_optimizer(eng_g, "adamw", {"lr": 1e-3, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+        traj = []
+        for _ in range(8):
+            traj.append(float(step()))
+            scaler.step(opt)
+            scaler.update()
+        assert step.captures == 1 and traj[-1] < traj[0]
+    finally:
+        _hip.seed_salt(0, add=False)
+
+
 def test_train_mode_dropout_and_recompute_match():
     """recompute (activation-checkpoint counterpart) replays the same dropout masks: identical gradients."""
     from climate_learn import manual_seed
