@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // Each wave walks LN_RPW consecutive rows (two passes per row: statistics, then dx from the L1/L2-hot
-// lines) and keeps its dgamma/dbeta partial sums in registers; one partial row per wave.
+// lines) and keeps its dgamma/dbeta partial sums in registers; one partial row per block (D % 4 == 0).
 constexpr int LN_RPW = 16;
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
@@ -130,18 +130,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
+  // the four waves' partial sums are combined in LDS (wave 0 stores, waves 1..3 add in turn): one partial row per
+  // block instead of four -> the reduce kernel reads a quarter of the data
+  extern __shared__ float ln_red[];            // [2][D]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int ch = lane + c * 64;
-    if (ch < nch) {
-      float* pg = part + ((size_t)pw * 2 + 0) * D + ch * 8;
-      float* pb = part + ((size_t)pw * 2 + 1) * D + ch * 8;
-      *reinterpret_cast<f32x4*>(pg) = (f32x4){dg[c][0], dg[c][1], dg[c][2], dg[c][3]};
-      *reinterpret_cast<f32x4*>(pg + 4) = (f32x4){dg[c][4], dg[c][5], dg[c][6], dg[c][7]};
-      *reinterpret_cast<f32x4*>(pb) = (f32x4){db[c][0], db[c][1], db[c][2], db[c][3]};
-      *reinterpret_cast<f32x4*>(pb + 4) = (f32x4){db[c][4], db[c][5], db[c][6], db[c][7]};
+      for (int c = 0; c < NC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float* a = ln_red + ch * 8 + j;
+            float* b = ln_red + D + ch * 8 + j;
+            *a = (w ? *a : 0.f) + dg[c][j];
+            *b = (w ? *b : 0.f) + db[c][j];
+          }
+        }
+      }
     }
+    __syncthreads();
   }
+  float* pout = part + (size_t)blockIdx.x * 2 * D;
+  for (int e = threadIdx.x * 4; e < 2 * D; e += 256 * 4)
+    *reinterpret_cast<f32x4*>(pout + e) = *reinterpret_cast<const f32x4*>(ln_red + e);
 }
 
 // out[which][col] = beta*out + sum_p part[p][which][col]; 32 columns x 8 partial-groups per block
@@ -450,12 +462,12 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
   hipStream_t s = (hipStream_t)stream;
   const int nc = (D / 8 + 63) / 64;
 #define CALL(N)                                                                                                  \
-  hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(nparts / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,   \
+  hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(nparts / 4), dim3(256), 2 * D * sizeof(float), s, (const bf16_t*)dy, (const bf16_t*)x, \
                      (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D)
   LN_DISPATCH(nc, CALL);
 #undef CALL
   O2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, nparts, D, dgamma, dbeta,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, nparts / 4, D, dgamma, dbeta,
                      grads_fp32, beta_acc);
   O2_CHECK_LAUNCH();
   return O2_OK;
