@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liborbit2_hip.so")
+# $ORBIT2_HIP_LIB: another build of the same ABI (A/B timing of kernel variants on one box; tools/ab_build.sh)
+LIB_PATH = os.environ.get("ORBIT2_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "liborbit2_hip.so")
 _lib = None
 
 

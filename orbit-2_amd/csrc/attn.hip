@@ -154,25 +154,16 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
-    // packed math where the ISA has it: v_pk_fma_f32 for the two exponent arguments of a register pair, v_pk_add_f32
-    // for two interleaved row-sum accumulators (the exponentials themselves are one v_exp_f32 each)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 psum2 = {0.f, 0.f};
-    const f32x2 sc2 = {sc_log2, sc_log2}, nm2 = {-m_run, -m_run};
+    float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 sv = {s[kb][r], s[kb][r + 1]};
-        const f32x2 a = __builtin_elementwise_fma(sv, sc2, nm2);
-        f32x2 p;
-        p[0] = __builtin_amdgcn_exp2f(a[0]);
-        p[1] = __builtin_amdgcn_exp2f(a[1]);
-        s[kb][r] = p[0];
-        s[kb][r + 1] = p[1];
-        psum2 += p;
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[kb][r] * sc_log2 - m_run);
+        s[kb][r] = p;
+        psum += p;
       }
-    l_run = l_run * alpha + (psum2[0] + psum2[1]);
+    l_run = l_run * alpha + psum;
     if (DROP) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -315,23 +306,11 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
       }
       if (DROP) drop_keys_in_regs(dp, rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
       const bool tail = RAGGED && (t == nt - 1) && (L & 63);
-      {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));     // packed fma / add / mul on register pairs
-        const f32x2 sc2 = {sc_log2, sc_log2}, nl2 = {-lse2, -lse2}, nd2 = {-dlt, -dlt};
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 a = __builtin_elementwise_fma((f32x2){s[r], s[r + 1]}, sc2, nl2);
-          f32x2 p;
-          p[0] = __builtin_amdgcn_exp2f(a[0]);
-          p[1] = __builtin_amdgcn_exp2f(a[1]);
-          if (tail) {                                                  // keys past the end of a ragged sequence
-            if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) p[0] = 0.f;
-            if (t * 64 + kb * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * hq >= L) p[1] = 0.f;
-          }
-          const f32x2 ds2 = p * ((f32x2){dp[r], dp[r + 1]} + nd2);     // dS^T
-          s[r] = ds2[0];
-          s[r + 1] = ds2[1];
-        }
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse2);
+        if (tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) p = 0.f;   // key past the end
+        s[r] = p * (dp[r] - dlt);  // dS^T
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
