@@ -4,17 +4,12 @@ Mirrors the reference package surface the driver uses (`import climate_learn as 
 `cl.data.IterDataModule`, the model / metrics registries, `FusedAttn`.  All compute goes through
 liborbit2_hip.so (include/orbit2_hip.h); there is no CPU fallback."""
 from .utils.fused_attn import FusedAttn
-from .utils.loaders import (
-    load_model_module,
-    load_forecasting_module,
-    load_climatebench_module,
-    load_downscaling_module,
-    load_architecture,
-    load_optimizer,
-    load_lr_scheduler,
-    load_loss,
-    load_transform,
-)
+from .utils import loaders as _loaders
+
+# the factory functions the reference re-exports at package level (src/climate_learn/__init__.py:1-11)
+_FACTORIES = ("load_model_module load_forecasting_module load_climatebench_module load_downscaling_module "
+              "load_architecture load_optimizer load_lr_scheduler load_loss load_transform").split()
+globals().update({_n: getattr(_loaders, _n) for _n in _FACTORIES})
 from . import data
 from .dist.dp_engine import HipDataParallel
 from .optim import HipAdamW, HipGradScaler
