@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--recompute", action="store_true", help="replay each Block in backward (activation ckpt)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay zero_grad+forward+loss+backward from one captured hipGraph (launch-bound small "
-                         "configurations; single GPU); the roofline fields then come from an eager instrumented pass")
+                    help="replay zero_grad+forward+loss+backward (+bucket all-reduces) from one captured hipGraph "
+                         "(launch-bound small configurations); the roofline fields then come from an eager "
+                         "instrumented pass")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter gradients, AdamW on 1/N of every unit, all-gather the bf16 copies")
     return ap.parse_args()
@@ -181,8 +182,6 @@ def main():
         step(i)
     fence()
     if a.graph:
-        if world > 1:
-            raise SystemExit("--graph is single-GPU (the engine's RCCL bookkeeping is not captured yet)")
         # instrumented eager pass for the per-kernel (roofline) numbers, then the captured step for the throughput
         _hip.timer = _hip.KernelTimer()
         for i in range(min(3, a.steps)):

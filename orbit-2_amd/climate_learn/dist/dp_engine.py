@@ -280,6 +280,7 @@ class HipDataParallel(nn.Module):
             if bk.handle:
                 for h in bk.handle:
                     h.wait()
+                bk.handle = None           # idempotent: a second call (e.g. scaler.step after a captured step) is a no-op
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 

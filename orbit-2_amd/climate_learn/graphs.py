@@ -9,8 +9,10 @@ Dropout / DropPath seeds are kernel ARGUMENTS, frozen at capture.  The captured 
 `orbit2_seed_salt(odd constant, add)`: a one-thread kernel that advances a device-side salt every seeded kernel xors into
 its seed, so each replay draws new masks while forward and backward of one replay still agree.
 
-Single-rank engines only for now: with more ranks the bucket all-reduces would have to be captured together with the
-comm-stream events (RCCL supports capture; the engine's bookkeeping of async handles does not yet)."""
+With several ranks (or ORBIT2_FORCE_COLLECTIVES=1) the engine's bucket all-reduces are issued during the captured
+backward on the communication stream; the body ends with `finish_grad_sync()`, which joins that stream back into the
+capture, so the collectives and their overlap with the rest of backward become part of the graph (RCCL supports stream
+capture).  Every rank must capture and replay in lock-step, as with any collective."""
 from typing import Optional
 
 import torch
@@ -23,8 +25,6 @@ SALT_STEP = 0x9E3779B97F4A7C15       # odd: the salt walks through all 2^64 valu
 
 class GraphedTrainStep:
     def __init__(self, engine, loss_metric, batch, var_weights, scaler=None, warmup: int = 2):
-        if getattr(engine, "world", 1) != 1:
-            raise NotImplementedError("GraphedTrainStep supports single-rank engines (see module docstring)")
         x, y, self.in_vars, self.out_vars = batch
         self.engine, self.loss_metric, self.var_weights, self.scaler = engine, loss_metric, var_weights, scaler
         self.device = engine.device
@@ -44,6 +44,7 @@ class GraphedTrainStep:
         loss = training_step((self.x, self.y, self.in_vars, self.out_vars), 0, self.engine, self.device,
                              self.var_weights, self.loss_metric)
         (loss * self.scale).backward()
+        self.engine.finish_grad_sync()               # joins the communication stream back into the captured stream
         return loss.detach()
 
     def capture(self):

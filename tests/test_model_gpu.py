@@ -235,6 +235,59 @@ def test_graphed_step_matches_eager_and_draws_new_masks():
         _hip.seed_salt(0, add=False)
 
 
+def test_graphed_step_captures_the_bucket_allreduces(monkeypatch):
+    """with the collectives forced on (single-rank RCCL group) the bucket all-reduces issued on the communication
+    stream during backward are captured into the hipGraph; replays keep producing the eager result"""
+    import torch.distributed as dist
+    import climate_learn as cl
+    from climate_learn import _hip, _ops
+    from climate_learn.graphs import GraphedTrainStep, SALT_STEP
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.testing import build_pair
+    from climate_learn.trainer import training_step
+    monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29657")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        vw = {"total_precipitation_24hr": 1.0}
+        loss_fn = Bayesian_TV(aggregate_only=True)
+
+        def fresh():
+            model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2, grid=(16, 32), B=2, seed=23)
+            eng = cl.HipDataParallel(model.cuda().train(), unit_types=(Block, nn.Sequential))
+            assert eng.force_comm and eng.comm_stream is not None
+            return eng, (x, y, in_vars, out_vars)
+
+        eng_e, batch = fresh()
+        cl.manual_seed(9)
+        _hip.seed_salt(3 * SALT_STEP, add=False)
+        eng_e.zero_grad()
+        le = training_step(batch, 0, eng_e, torch.device("cuda"), vw, loss_fn)
+        le.backward()
+        eng_e.finish_grad_sync()
+        g_e = eng_e.g16.clone()
+        eng_g, batch = fresh()
+        cl.manual_seed(9)
+        _hip.seed_salt(0, add=False)
+        step = GraphedTrainStep(eng_g, loss_fn, batch, vw)
+        l1 = float(step())
+        assert l1 == float(le) and torch.equal(eng_g.g16, g_e)
+        opt = cl.load_optimizer(eng_g, "adamw", {"lr": 1e-3, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+        traj = []
+        for _ in range(6):
+            traj.append(float(step()))
+            opt.step()
+        assert step.captures == 1 and traj[-1] < traj[0]
+    finally:
+        _hip.seed_salt(0, add=False)
+        if created:
+            dist.destroy_process_group()
+
+
 def test_train_mode_dropout_and_recompute_match():
     """recompute (activation-checkpoint counterpart) replays the same dropout masks: identical gradients."""
     from climate_learn import manual_seed
