@@ -143,10 +143,11 @@ int orbit2_loss_fwd(const float* pred, const float* target, int Ht, int Wt, cons
 int orbit2_loss_bwd(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, const float* chan_w,
                     const float* gscale, float* dpred, int B, int C, int H, int W, int kind, void* stream);
 
-/* evaluation metrics (metrics/functional.py:236-324 rmse / pearson / mean_bias): out[b][c][6] (double) =
- * {sum p, sum t, sum p^2, sum t^2, sum p*t, sum w_lat (p-t)^2} over the H*W pixels (target: top-left crop) */
-int orbit2_eval_moments(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, double* out, int B,
-                        int C, int H, int W, void* stream);
+/* evaluation metrics (metrics/functional.py:219-324 mae / rmse / acc / pearson / mean_bias): out[b][c][12] (double),
+ * with a = pred - clim, b = target - clim (clim fp32 [C][H][W] or NULL; target: top-left crop), w = lat_w[y] or 1:
+ * {sum a, sum b, sum a^2, sum b^2, sum ab, sum w(a-b)^2, sum w|a-b|, sum wa, sum wb, sum w ab, sum w a^2, sum w b^2} */
+int orbit2_eval_moments(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, const float* clim,
+                        double* out, int B, int C, int H, int W, void* stream);
 
 /* ---- perceptual loss = L1 + 0.5 * mean_b LPIPS-VGG16 (metrics/functional.py:17-33, metrics.py:119-187) ------
  * Feature maps are NHWC bf16, so each 3x3 VGG convolution is im2col + orbit2_gemm_bf16 (bias, act = 2) forward and

@@ -431,6 +431,28 @@ def mean_bias(pred, target, aggregate_only=False):
     return _reduce_vec(target.mean((0, 2, 3)) - pred.mean((0, 2, 3)), aggregate_only)
 
 
+def mae(pred, target, aggregate_only=False, lat_w=None):
+    """:219-232: mean absolute (latitude-weighted) error per channel and overall"""
+    err = (pred - target).abs()
+    if lat_w is not None:
+        err = err * lat_w
+    per = err.mean([0, 2, 3])
+    return err.mean() if aggregate_only else torch.cat((per, err.mean().unsqueeze(0)))
+
+
+def acc(pred, target, climatology, aggregate_only=False, lat_w=None):
+    """:259-291: anomaly correlation; channels centred by their unweighted mean, latitude-weighted sums (the
+    reference's mask branch is overwritten by the unmasked sums, so there is no mask here)"""
+    w = lat_w if lat_w is not None else torch.ones(1, 1, pred.shape[2], 1)
+    a, b = pred - climatology, target - climatology
+    per = []
+    for i in range(pred.shape[1]):
+        pa, pb = a[:, i] - a[:, i].mean(), b[:, i] - b[:, i].mean()
+        ww = w[0]                                                     # [1,H,1] against [B,H,W]
+        per.append((ww * pa * pb).sum() / ((ww * pa.square()).sum() * (ww * pb.square()).sum()).sqrt())
+    return _reduce_vec(torch.stack(per), aggregate_only)
+
+
 def _reduce_vec(per_channel, aggregate_only):
     agg = per_channel.mean()
     return agg if aggregate_only else torch.cat((per_channel, agg.unsqueeze(0)))

@@ -481,13 +481,17 @@ def l1_mean(a, b, out):
     _chk(lib().orbit2_l1_mean(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "orbit2_l1_mean")
 
 
-def eval_moments(pred, target, lat_w=None):
-    """[B,C,6] float64: sum p, sum t, sum p^2, sum t^2, sum p*t, sum w_lat (p-t)^2 per image (target top-left crop)"""
+def eval_moments(pred, target, lat_w=None, clim=None):
+    """[B,C,12] float64 sums over a = pred - clim, b = target - clim (see include/orbit2_hip.h:orbit2_eval_moments)"""
     _dev(pred, F32, "pred"); _dev(target, F32, "target")
     B, Cc, H, W = pred.shape
-    out = torch.empty(B, Cc, 6, dtype=torch.float64, device=pred.device)
-    _chk(lib().orbit2_eval_moments(_p(pred), _p(target), target.shape[2], target.shape[3], _p(lat_w), _p(out), B, Cc, H,
-                                   W, _stream()), "orbit2_eval_moments")
+    if clim is not None:
+        _dev(clim, F32, "clim")
+        if tuple(clim.shape[-3:]) != (Cc, H, W):
+            raise HipBackendError("climatology must be [C,H,W] of the prediction's size")
+    out = torch.empty(B, Cc, 12, dtype=torch.float64, device=pred.device)
+    _chk(lib().orbit2_eval_moments(_p(pred), _p(target), target.shape[2], target.shape[3], _p(lat_w), _p(clim), _p(out),
+                                   B, Cc, H, W, _stream()), "orbit2_eval_moments")
     return out
 
 

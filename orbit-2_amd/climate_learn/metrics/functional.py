@@ -57,12 +57,16 @@ def image_gradient(pred, target, var_names: Optional[List[str]] = None, var_weig
 
 
 # ---- evaluation metrics (reference :236-324); one reduction kernel, the [B,C,6] -> [C+1] algebra on the host ----------
-def _moments(pred, target, lat_weights=None):
+def _moments(pred, target, lat_weights=None, climatology=None):
     from .. import _hip
     if isinstance(pred, torch.distributions.Normal):
         pred = pred.loc
+    clim = None
+    if climatology is not None:
+        clim = climatology.detach().to(device=pred.device, dtype=torch.float32)
+        clim = clim.reshape(-1, *clim.shape[-2:])[:, : pred.shape[2], : pred.shape[3]].contiguous()
     return _hip.eval_moments(pred.detach().float().contiguous(), target.detach().float().contiguous(),
-                             _lat(lat_weights, pred)), pred.shape[2] * pred.shape[3]
+                             _lat(lat_weights, pred), clim), pred.shape[2] * pred.shape[3]
 
 
 def _with_aggregate(per_channel, aggregate_only):
@@ -94,3 +98,29 @@ def mean_bias(pred, target, aggregate_only: bool = False):
     m, n = _moments(pred, target)
     s = m.sum(0)
     return _with_aggregate(((s[:, 1] - s[:, 0]) / (n * pred.shape[0])).float(), aggregate_only)
+
+
+def mae(pred, target, aggregate_only: bool = False, lat_weights=None):
+    """mean |pred - target| (x latitude weight) per channel and over everything (reference :219-232; with equal
+    channel sizes the overall mean is the mean of the channel means)."""
+    m, n = _moments(pred, target, lat_weights)
+    return _with_aggregate((m[..., 6].sum(0) / (n * pred.shape[0])).float(), aggregate_only)
+
+
+def acc(pred, target, climatology, aggregate_only: bool = False, lat_weights=None, mask=None):
+    """anomaly correlation (reference :259-291): anomalies w.r.t. the climatology, each channel centred by its
+    unweighted mean over (B,H,W), latitude-weighted covariance / sqrt(variances).  The reference's `mask` argument has
+    no effect there (its masked sums are overwritten by the unmasked ones, :282-284) and is ignored here; without
+    latitude weights the reference raises (None * tensor) -- unit weights are used instead."""
+    m, n = _moments(pred, target, lat_weights, climatology)
+    s = m.sum(0)                                        # [C,12] over the batch
+    N = n * pred.shape[0]
+    ma, mb = s[:, 0] / N, s[:, 1] / N
+    if lat_weights is None:
+        sw = torch.full_like(ma, float(N))
+    else:
+        sw = _lat(lat_weights, pred).double().sum() * pred.shape[3] * pred.shape[0]
+    cov = s[:, 9] - ma * s[:, 8] - mb * s[:, 7] + ma * mb * sw
+    va = s[:, 10] - 2 * ma * s[:, 7] + ma * ma * sw
+    vb = s[:, 11] - 2 * mb * s[:, 8] + mb * mb * sw
+    return _with_aggregate((cov / (va * vb).sqrt()).float(), aggregate_only)

@@ -7,7 +7,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .functional import bayesian_tv, image_gradient, mean_bias, mse, pearson, rmse
+from .functional import acc, bayesian_tv, image_gradient, mae, mean_bias, mse, pearson, rmse
 from .utils import MetricsMetaInfo, register
 
 
@@ -112,14 +112,32 @@ class LatWeightedRMSE(LatitudeWeightedMetric):
         return rmse(pred, target, self.aggregate_only, self.lat_weights, mask)
 
 
-def _not_on_path(name):
-    class _M(Metric):
-        def __call__(self, *a, **k):
-            raise NotImplementedError(
-                "%s is an evaluation metric outside the training hot path of this build" % name)
-    _M.__name__ = name.upper()
-    return register(name)(_M)
+@register("mae")
+class MAE(Metric):
+    def __call__(self, pred, target):
+        return mae(pred, target, self.aggregate_only)
 
 
-for _n in ("mae", "lat_acc", "acc"):
-    _not_on_path(_n)
+class ClimatologyBasedMetric(Metric):
+    """metrics that subtract the split's climatology (reference metrics.py:78-97): metainfo.climatology is [C,H,W]"""
+
+    def __init__(self, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None):
+        Metric.__init__(self, aggregate_only, metainfo)
+        self.climatology = self.metainfo.climatology.unsqueeze(0)
+
+
+@register("acc")
+class ACC(ClimatologyBasedMetric):
+    def __call__(self, pred, target, mask=None):
+        return acc(pred, target, self.climatology, self.aggregate_only, None, mask)
+
+
+@register("lat_acc")
+class LatWeightedACC(LatitudeWeightedMetric, ClimatologyBasedMetric):
+    def __init__(self, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None):
+        LatitudeWeightedMetric.__init__(self, aggregate_only, metainfo)
+        ClimatologyBasedMetric.__init__(self, aggregate_only, metainfo)
+
+    def __call__(self, pred, target, mask=None):
+        self.cast_to_device(pred)
+        return acc(pred, target, self.climatology, self.aggregate_only, self.lat_weights, mask)

@@ -433,46 +433,58 @@ extern "C" int orbit2_loss_bwd(const float* pred, const float* target, int Ht, i
   return O2_OK;
 }
 
-// ---- evaluation metrics (metrics/functional.py:236-324: rmse, pearson, mean_bias) ---------------------------------------
-// six sums per (b, c) image: sum p, sum t, sum p^2, sum t^2, sum p*t, sum (p-t)^2 (optionally latitude-weighted);
+// ---- evaluation metrics (metrics/functional.py:219-324: mae, rmse, acc, pearson, mean_bias) ------------------------------
+// twelve sums per (b, c) image over a = pred - clim, b = target - clim (clim optional, [C][H][W]), w = lat_w[y] or 1:
+//   0 sum a, 1 sum b, 2 sum a^2, 3 sum b^2, 4 sum a*b, 5 sum w (a-b)^2, 6 sum w |a-b|,
+//   7 sum w a, 8 sum w b, 9 sum w a*b, 10 sum w a^2, 11 sum w b^2
 // per-thread fp32 partials, double accumulation across the grid.
 namespace {
+constexpr int EVAL_NM = 12;
 __global__ __launch_bounds__(256) void eval_moments_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                            int Ht, int Wt, const float* __restrict__ lat_w,
-                                                           double* __restrict__ out, int C, int H, int W) {
-  __shared__ float red[4][6];
+                                                           const float* __restrict__ clim, double* __restrict__ out,
+                                                           int C, int H, int W) {
+  __shared__ float red[4][EVAL_NM];
   const int bc = blockIdx.y;
   const float* p = pred + (size_t)bc * H * W;
   const float* t = target + (size_t)bc * Ht * Wt;
-  float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* cl = clim ? clim + (size_t)(bc % C) * H * W : nullptr;
+  float s[EVAL_NM];
+#pragma unroll
+  for (int k = 0; k < EVAL_NM; ++k) s[k] = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
     const int y = i / W, x = i - y * W;
-    const float a = p[i], b = t[(size_t)y * Wt + x];
+    const float c0 = cl ? cl[i] : 0.f;
+    const float a = p[i] - c0, b = t[(size_t)y * Wt + x] - c0;
+    const float w = lat_w ? lat_w[y] : 1.f;
     const float d = a - b;
     s[0] += a; s[1] += b; s[2] += a * a; s[3] += b * b; s[4] += a * b;
-    s[5] += lat_w ? d * d * lat_w[y] : d * d;
+    s[5] += w * d * d; s[6] += w * fabsf(d);
+    s[7] += w * a; s[8] += w * b; s[9] += w * a * b; s[10] += w * a * a; s[11] += w * b * b;
   }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < EVAL_NM; ++k) {
     const float v = wave_sum(s[k]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < EVAL_NM) {
     const int k = threadIdx.x;
-    atomicAdd(out + (size_t)bc * 6 + k, (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k]);
+    atomicAdd(out + (size_t)bc * EVAL_NM + k,
+              (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k]);
   }
 }
 }  // namespace
 
-extern "C" int orbit2_eval_moments(const float* pred, const float* target, int Ht, int Wt, const float* lat_w, double* out,
-                                   int B, int C, int H, int W, void* stream) {
+extern "C" int orbit2_eval_moments(const float* pred, const float* target, int Ht, int Wt, const float* lat_w,
+                                   const float* clim, double* out, int B, int C, int H, int W, void* stream) {
   if (!pred || !target || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ht < H || Wt < W) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(double) * (size_t)B * C * 6, s) != hipSuccess) return O2_ERR_LAUNCH;
+  if (hipMemsetAsync(out, 0, sizeof(double) * (size_t)B * C * EVAL_NM, s) != hipSuccess) return O2_ERR_LAUNCH;
   int nblk = (H * W + 256 * 8 - 1) / (256 * 8);
   if (nblk > 64) nblk = 64;
-  hipLaunchKernelGGL(eval_moments_kernel, dim3(nblk, B * C), dim3(256), 0, s, pred, target, Ht, Wt, lat_w, out, C, H, W);
+  hipLaunchKernelGGL(eval_moments_kernel, dim3(nblk, B * C), dim3(256), 0, s, pred, target, Ht, Wt, lat_w, clim, out, C,
+                     H, W);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

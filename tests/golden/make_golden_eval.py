@@ -30,6 +30,11 @@ def main():
            "lat_rmse": t2n(fn.rmse(pred, target, False, wl)),
            "pearson": t2n(fn.pearson(pred, target, False)), "pearson.agg": t2n(fn.pearson(pred, target, True)),
            "mean_bias": t2n(fn.mean_bias(pred, target, False)), "mean_bias.agg": t2n(fn.mean_bias(pred, target, True))}
+    clim = torch.randn(3, 24, 40, generator=g) * 0.5
+    out.update({"clim": t2n(clim), "mae": t2n(fn.mae(pred, target, False)), "lat_mae": t2n(fn.mae(pred, target, False, wl)),
+                "lat_acc": t2n(fn.acc(pred, target, clim.unsqueeze(0), False, wl)),
+                "lat_acc.agg": t2n(fn.acc(pred, target, clim.unsqueeze(0), True, wl)),
+                "acc_unit_weights": t2n(fn.acc(pred, target, clim.unsqueeze(0), False, torch.ones_like(wl)))})
     np.savez_compressed(os.path.join(OUT, "eval_metrics.npz"), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -23,6 +23,16 @@ def test_eval_metrics_match_reference_golden(golden_dir):
     for n in ("rmse", "pearson", "mean_bias"):
         m = METRICS_REGISTRY[n](aggregate_only=True, metainfo=meta)
         assert np.allclose(float(m(pred, target)), z[n + ".agg"], rtol=2e-5, atol=2e-6)
+    # mae / anomaly correlation (forecasting-side metrics of the registry), climatology [C,H,W]
+    clim = torch.from_numpy(z["clim"])
+    meta_c = MetricsMetaInfo(["a", "b", "c"], ["a", "b", "c"], z["lat"], np.zeros(40), clim)
+    assert np.allclose(METRICS_REGISTRY["mae"](aggregate_only=False, metainfo=meta_c)(pred, target).cpu().numpy(), z["mae"], rtol=2e-5)
+    assert np.allclose(fn.mae(pred, target, False, torch.from_numpy(np.cos(np.deg2rad(z["lat"])) / np.cos(np.deg2rad(z["lat"])).mean()).float().view(1, 1, -1, 1)).cpu().numpy(),
+                       z["lat_mae"], rtol=2e-5)
+    la = METRICS_REGISTRY["lat_acc"](aggregate_only=False, metainfo=meta_c)
+    assert np.allclose(la(pred, target).cpu().numpy(), z["lat_acc"], rtol=5e-5, atol=5e-6)
+    ua = METRICS_REGISTRY["acc"](aggregate_only=False, metainfo=meta_c)
+    assert np.allclose(ua(pred, target).cpu().numpy(), z["acc_unit_weights"], rtol=5e-5, atol=5e-6)
     # a target larger than the prediction is consumed through its top-left crop
     big = torch.zeros(3, 3, 30, 47, device="cuda")
     big[:, :, :24, :40] = target

@@ -206,3 +206,9 @@ def test_eval_metrics_match_reference(golden_dir):
     assert np.allclose(float(O.rmse(pred, target, True)), z["rmse.agg"], rtol=2e-5)
     assert np.allclose(float(O.pearson(pred, target, True)), z["pearson.agg"], rtol=2e-5)
     assert np.allclose(float(O.mean_bias(pred, target, True)), z["mean_bias.agg"], rtol=2e-5, atol=2e-6)
+    clim = torch.from_numpy(z["clim"]).unsqueeze(0)
+    assert np.allclose(O.mae(pred, target).numpy(), z["mae"], rtol=2e-5)
+    assert np.allclose(O.mae(pred, target, False, lw).numpy(), z["lat_mae"], rtol=2e-5)
+    assert np.allclose(O.acc(pred, target, clim, False, lw).numpy(), z["lat_acc"], rtol=2e-5, atol=2e-6)
+    assert np.allclose(float(O.acc(pred, target, clim, True, lw)), z["lat_acc.agg"], rtol=2e-5, atol=2e-6)
+    assert np.allclose(O.acc(pred, target, clim).numpy(), z["acc_unit_weights"], rtol=2e-5, atol=2e-6)
