@@ -274,7 +274,7 @@ def _tables(sd, heads, ids, D):
 
 
 @pytest.mark.parametrize("D,heads,V,hw", [(64, 4, 5, (8, 16)), (256, 4, 23, (16, 32)), (384, 3, 7, (12, 20)),
-                                           (256, 2, 25, (32, 64)), (512, 2, 5, (8, 16))])
+                                           (256, 2, 25, (32, 64)), (512, 2, 5, (8, 16)), (256, 4, 30, (8, 16))])
 def test_varagg_fold_matches_dense_oracle(hip, D, heads, V, hw):
     cfg = O.Config(["v%d" % i for i in range(V + 2)], hw, 1, D, 1, 1, heads)
     sd = O.init_state_dict(cfg, V, seed=1)
