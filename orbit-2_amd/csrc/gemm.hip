@@ -290,19 +290,25 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
       stage_tile<A_KC>(A, lda, m0, M, (kt + 1) * BK, K, na, wave, lane);
       stage_tile<B_KC>(B, ldb, n0, N, (kt + 1) * BK, K, na + TILE_BYTES, wave, lane);
     }
+    // both k-halves' fragments are read up front (the second half lands under the first half's MFMAs), and the
+    // MFMA bursts run at raised priority so the co-resident workgroup's loads do not break them up
+    bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(sa, wm * 64 + i * 16, kk, lane);
+      for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag<A_KC>(sa, wm * 64 + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(sb, wn * 64 + j * 16, kk, lane);
+      for (int j = 0; j < 4; ++j) fb[kk][j] = read_frag<B_KC>(sb, wn * 64 + j * 16, kk, lane);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
