@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   const int orig = blockIdx.x;
   const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  constexpr int GROUP = 4;
+  constexpr int GROUP = 2;
   const int per_group = GROUP * tiles_n;
   const int grp = id / per_group;
   const int first_m = grp * GROUP;

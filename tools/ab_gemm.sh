@@ -3,5 +3,5 @@
 R=$GRAFT_REPO_ROOT
 for tag in base alt base alt; do
   lib=""; [ "$tag" = alt ] && lib="$R/orbit-2_amd/lib/alt/$1.so"
-  echo "== $tag"; ORBIT2_HIP_LIB=$lib python3 $R/tools/dw_ab.py
+  echo "== $tag"; ORBIT2_HIP_LIB=$lib python3 $R/tools/${AB_SCRIPT:-dw_ab.py} $AB_ARGS
 done
