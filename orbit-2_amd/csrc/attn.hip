@@ -59,6 +59,21 @@ __device__ __forceinline__ void stage_keyhash(uint32_t* skh, uint64_t seed, int 
   if (tid < 16) skh[(tid & 1) * 8 + (tid >> 1)] = o2_attn_keyhash(seed, (uint32_t)(tile * 16 + tid));
 }
 
+// Workgroup -> (128-row tile, head, batch).  The grid is launched one-dimensional; hardware deals consecutive
+// workgroups round-robin to the 8 XCDs, so the id is first remapped (bijectively, any grid size) to give every XCD a
+// CONTIGUOUS range of tile ids: the ~64 workgroups an XCD runs at a time are then consecutive tiles of one or two
+// (batch, head) pairs and share that pair's K/V (or Q/dO) through the XCD's L2, instead of every XCD streaming the
+// tiles of eight different heads.
+__device__ __forceinline__ void attn_tile_coords(int nq, int H, int& qt, int& head, int& b) {
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  qt = id % nq;
+  const int grp = id / nq;
+  head = grp % H;
+  b = grp / H;
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -73,8 +88,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;  // MFMA half
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int tile_i, head, b;
+  attn_tile_coords((L + 127) / 128, H, tile_i, head, b);
+  const int q0 = tile_i * 128 + wave * 32;
   const size_t tstride = (size_t)3 * H * D;  // token stride in qkv
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -249,8 +265,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int tile_i, head, b;
+  attn_tile_coords((L + 127) / 128, H, tile_i, head, b);
+  const int q0 = tile_i * 128 + wave * 32;
   const size_t tstride = (size_t)3 * H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -359,8 +376,9 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  int tile_i, head, b;
+  attn_tile_coords((L + 127) / 128, H, tile_i, head, b);
+  const int k0 = tile_i * 128 + wave * 32;
   const size_t tstride = (size_t)3 * H * D;
   const size_t ostride = (size_t)H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
@@ -553,7 +571,7 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   const float sc_log2 = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
-  dim3 grid((L + 127) / 128, H, B), block(256);
+  dim3 grid(((L + 127) / 128) * H * B), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool ragged = (L % 128) != 0;
 #define O2_FWD(DV, DR)                                                                                              \
@@ -586,7 +604,7 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, s,
                      (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
   O2_CHECK_LAUNCH();
-  dim3 grid((L + 127) / 128, H, B), block(256);
+  dim3 grid(((L + 127) / 128) * H * B), block(256);
   const bf16_t* q_ = (const bf16_t*)qkv;
   const bf16_t* do_ = (const bf16_t*)dout;
   bf16_t* dq_ = (bf16_t*)dqkv;
