@@ -111,9 +111,12 @@ def main():
                 if world_rank == 0:
                     print("load pretrained model", tr["pretrain"], flush=True)
                 cl.utils.load_pretrained_weights(model, str(tr["pretrain"]), verbose=world_rank == 0)
-            print("enter NO SHARD only,", flush=True)
+            # parallelism.fsdp > 1 asks the reference for sharded FSDP (HYBRID/FULL_SHARD, :583-617); here it selects the
+            # sharded-optimizer engine (reduce-scatter + AdamW on 1/N + all-gather) over the whole data-parallel group
+            shard = fsdp_size > 1 and world_size > 1
+            print("enter sharded optimizer (SHARD_GRAD_OP-like)," if shard else "enter NO SHARD only,", flush=True)
             eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
-                                     sync_module_states=True)
+                                     sync_module_states=True, shard_optimizer=shard)
             for blk in model.blocks:
                 blk.recompute = bool(tr.get("activation_checkpointing", False))
             optimizer = cl.load_optimizer(eng, "adamw", {"lr": float(mc["lr"]), "weight_decay": float(mc["weight_decay"]),
