@@ -16,6 +16,17 @@ def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
+def _source_digest(srcs, hdrs) -> str:
+    """content hash of everything the library is built from (file times do not survive a snapshot copy)"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in sorted([os.path.join(CSRC, s) for s in srcs] + hdrs):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
@@ -23,6 +34,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "orbit2_hip.h"))
+    digest, stamp = _source_digest(srcs, hdrs), LIB + ".srchash"
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return LIB                  # the shipped library was built from exactly these sources
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
@@ -50,6 +64,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
         if verbose:
             print("[orbit2 build] linked", LIB, flush=True)
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return LIB
 
 
