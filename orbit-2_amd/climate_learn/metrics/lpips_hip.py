@@ -24,18 +24,18 @@ _TV_CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
 
 def random_lpips_state(seed: int = 0) -> Dict[str, torch.Tensor]:
     """He-normal convolutions, small positive lins -- same recipe as the test oracle's stand-in weights."""
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device="cpu").manual_seed(seed)      # CPU draws even inside a `with torch.device("cuda")` block
     sd, cin, i = {}, 3, 0
     for c in VGG16_CFG:
         if c == "M":
             continue
-        sd["conv%d.weight" % i] = torch.randn(c, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
-        sd["conv%d.bias" % i] = torch.randn(c, generator=g) * 0.05
+        sd["conv%d.weight" % i] = torch.randn(c, cin, 3, 3, generator=g, device="cpu") * math.sqrt(2.0 / (9 * cin))
+        sd["conv%d.bias" % i] = torch.randn(c, generator=g, device="cpu") * 0.05
         cin = c
         i += 1
     for k, ci in enumerate(VGG16_TAPS):
         ch = sd["conv%d.weight" % ci].shape[0]
-        sd["lin%d.weight" % k] = torch.rand(ch, generator=g) * (2.0 / ch)
+        sd["lin%d.weight" % k] = torch.rand(ch, generator=g, device="cpu") * (2.0 / ch)
     return sd
 
 

@@ -45,6 +45,22 @@ def test_training_driver_trains_checkpoints_and_resumes(tmp_path):
     assert re.findall(r"epoch:  (\d+) batch_idx 0 ", out2) == ["3"]                 # continues at epoch 3 only
 
 
+def test_training_driver_daymet_like_perceptual_loss(tmp_path):
+    """configs/interm_1b_daymet.yaml (7 inputs, 3 outputs, hybrid perceptual loss) with a reduced model and grid"""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_1b_daymet.yaml")))
+    assert conf["trainer"]["train_loss"] == "perceptual" and len(conf["data"]["dict_in_variables"]["DAYMET_1"]) == 7
+    conf["trainer"].update(max_epochs=2, batch_size=2)
+    conf["model"].update(embed_dim=256, depth=2, decoder_depth=1, num_heads=4, warmup_epochs=1)
+    conf["data"]["synthetic"]["DAYMET_1"].update(lowres_hw=[32, 64], highres_hw=[128, 256], steps_per_epoch=3)
+    cfg = os.path.join(tmp_path, "daymet.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("intermediate_downscaling.py", cfg, tmp_path)
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 6 and all(l == l and 0 < l < 1e3 for l in losses)
+    assert losses[-1] < losses[0]                                   # L1 + LPIPS descends on the fixed synthetic batch set
+    assert os.path.exists(os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt"))
+
+
 def test_inference_driver_reports_stitched_metrics(tmp_path):
     conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "inference.yaml")))
     conf["model"].update(embed_dim=256, depth=2, decoder_depth=1, num_heads=4)
