@@ -45,6 +45,20 @@ def test_training_driver_trains_checkpoints_and_resumes(tmp_path):
     assert re.findall(r"epoch:  (\d+) batch_idx 0 ", out2) == ["3"]                 # continues at epoch 3 only
 
 
+@pytest.mark.parametrize("loss_name", ["mse", "lat_mse", "imagegradient"])
+def test_training_driver_other_registered_losses(tmp_path, loss_name):
+    """every other training loss the YAML may name runs through the same driver"""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=2, train_loss=loss_name)
+    conf["model"].update(depth=1, warmup_epochs=1)
+    conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=2)
+    cfg = os.path.join(tmp_path, "l.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("intermediate_downscaling.py", cfg, tmp_path)
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 4 and all(l == l and 0 < l < 1e4 for l in losses)
+
+
 def test_training_driver_daymet_like_perceptual_loss(tmp_path):
     """configs/interm_1b_daymet.yaml (7 inputs, 3 outputs, hybrid perceptual loss) with a reduced model and grid"""
     conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_1b_daymet.yaml")))
