@@ -59,6 +59,23 @@ def test_training_driver_other_registered_losses(tmp_path, loss_name):
     assert len(losses) == 4 and all(l == l and 0 < l < 1e4 for l in losses)
 
 
+def test_training_driver_with_spatial_tiling(tmp_path):
+    """tiling.do_tiling: the data module hands out div x div tiles with an overlap halo (32x64 field, div 2, overlap 2 ->
+    18x36 tiles, 162 tokens per sample: ragged attention tiles and odd GEMM row counts in a real run)"""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=3)
+    conf["tiling"] = {"do_tiling": True, "div": 2, "overlap": 2}
+    conf["model"].update(depth=2, warmup_epochs=1)
+    conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=2)
+    cfg = os.path.join(tmp_path, "t.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("intermediate_downscaling.py", cfg, tmp_path)
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 4 and all(l == l and 0 < l < 1e4 for l in losses)
+    ck = torch.load(os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt"), map_location="cpu")
+    assert ck["model_state_dict"]["pos_embed"].shape[1] == 9 * 18
+
+
 def test_training_driver_daymet_like_perceptual_loss(tmp_path):
     """configs/interm_1b_daymet.yaml (7 inputs, 3 outputs, hybrid perceptual loss) with a reduced model and grid"""
     conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_1b_daymet.yaml")))
