@@ -59,6 +59,26 @@ def test_training_driver_other_registered_losses(tmp_path, loss_name):
     assert len(losses) == 4 and all(l == l and 0 < l < 1e4 for l in losses)
 
 
+def test_training_driver_float32_flag_and_activation_checkpointing(tmp_path):
+    """trainer.data_type float32 (no loss scaler; the kernels still compute in bf16 on fp32 masters) together with
+    trainer.activation_checkpointing (each Block's forward is replayed in backward with the same dropout seeds)"""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=2, data_type="float32", activation_checkpointing=True)
+    conf["model"].update(depth=2, warmup_epochs=1)
+    conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=2)
+    cfg = os.path.join(tmp_path, "f.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("intermediate_downscaling.py", cfg, tmp_path)
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 4 and all(l == l and 0 < l < 1e4 for l in losses)
+    bad = dict(conf)
+    bad["trainer"] = dict(conf["trainer"], data_type="float16")
+    yaml.safe_dump(bad, open(cfg, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "intermediate_downscaling.py"), cfg], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "Data type not supported" in r.stderr
+
+
 def test_training_driver_with_spatial_tiling(tmp_path):
     """tiling.do_tiling: the data module hands out div x div tiles with an overlap halo (32x64 field, div 2, overlap 2 ->
     18x36 tiles, 162 tokens per sample: ragged attention tiles and odd GEMM row counts in a real run)"""
