@@ -79,6 +79,56 @@ def test_training_driver_float32_flag_and_activation_checkpointing(tmp_path):
     assert r.returncode != 0 and "Data type not supported" in r.stderr
 
 
+def _write_npz_tree(root, hw, variables, rng):
+    """reference on-disk format (data/processing/nc2npz.py): <root>/{train,val,test}/<year>_<shard>.npz var -> [T,1,H,W],
+    lat.npy, lon.npy, normalize_{mean,std}.npz, <split>/climatology.npz"""
+    import numpy as np
+    H, W = hw
+    for split in ("train", "val", "test"):
+        os.makedirs(os.path.join(root, split))
+        for sh in range(2):
+            np.savez(os.path.join(root, split, "2000_%d.npz" % sh),
+                     **{v: (np.abs(rng.normal(size=(3, 1, H, W))) * 1e-3 if "precip" in v else rng.normal(size=(3, 1, H, W)) + 270.0)
+                        for v in variables})
+        np.savez(os.path.join(root, split, "climatology.npz"), **{v: np.zeros((1, H, W)) for v in variables})
+    np.save(os.path.join(root, "lat.npy"), np.linspace(-80, 80, H))
+    np.save(os.path.join(root, "lon.npy"), np.linspace(0, 350, W))
+    np.savez(os.path.join(root, "normalize_mean.npz"), **{v: np.array([0.5e-3 if "precip" in v else 270.0]) for v in variables})
+    np.savez(os.path.join(root, "normalize_std.npz"), **{v: np.array([1e-3 if "precip" in v else 1.0]) for v in variables})
+
+
+def test_drivers_over_an_on_disk_npz_tree(tmp_path):
+    """the npz data plane end to end: both drivers read a reference-format directory tree (file sharding, tiling,
+    normalisation, log-precipitation, Denormalize with the stored statistics)"""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    consts = ["land_sea_mask", "orography", "lattitude", "landcover"]
+    outs = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+    lo, hi = os.path.join(tmp_path, "lo"), os.path.join(tmp_path, "hi")
+    _write_npz_tree(lo, (32, 64), consts + outs, rng)
+    _write_npz_tree(hi, (128, 256), outs, rng)
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=3, buffer_size=4)
+    conf["model"].update(depth=2, warmup_epochs=1)
+    conf["data"].update(low_res_dir={"ERA5_1": lo}, high_res_dir={"ERA5_1": hi}, default_vars=consts + outs,
+                        dict_in_variables={"ERA5_1": consts + outs}, dict_out_variables={"ERA5_1": outs})
+    conf["data"].pop("synthetic", None)
+    cfg = os.path.join(tmp_path, "disk.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("intermediate_downscaling.py", cfg, tmp_path)
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 2 * 2 and all(l == l and 0 < l < 1e4 for l in losses)   # 6 samples / batch 3, two epochs
+    conf["trainer"].update(pretrain=os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt"), batch_size=1)
+    conf["tiling"] = {"do_tiling": True, "div": 2, "overlap": 4}
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("visualize.py", cfg, tmp_path)
+    assert "load pretrained model" in out and "(128, 256)" in out
+    m = re.search(r"rmse \[([^\]]+)\]", out)
+    vals = [float(v) for v in m.group(1).split(",")]
+    assert len(vals) == 4 and all(v == v and v > 0 for v in vals)
+    assert vals[1] < 50.0                        # temperatures are compared in kelvin (denormalised), errors of a few K
+
+
 def test_training_driver_with_spatial_tiling(tmp_path):
     """tiling.do_tiling: the data module hands out div x div tiles with an overlap halo (32x64 field, div 2, overlap 2 ->
     18x36 tiles, 162 tokens per sample: ragged attention tiles and odd GEMM row counts in a real run)"""
