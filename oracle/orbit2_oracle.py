@@ -70,10 +70,14 @@ def patch_embed(x1: torch.Tensor, w: torch.Tensor, b: torch.Tensor, patch: int) 
     return y.flatten(2).transpose(1, 2)
 
 
-def mha_core(q, k, v, scale):
-    """components/attention.py:72-78 (FusedAttn.NONE branch); q,k,v: [B, H, N, d]."""
+def mha_core(q, k, v, scale, pmask=None):
+    """components/attention.py:72-78 (FusedAttn.NONE branch); q,k,v: [B, H, N, d].  pmask: optional multiplier on the
+    attention probabilities = keep mask x 1/(1-p) of `attn_drop` (attention.py:76), supplied by tests that replicate
+    the kernels' dropout masks."""
     a = (q * scale) @ k.transpose(-2, -1)
     a = a.softmax(dim=-1)
+    if pmask is not None:
+        a = a * pmask
     return a @ v
 
 
@@ -89,29 +93,43 @@ def variable_aggregation(x_bvld, var_query, wq, wkv, wp, bp, heads: int):
     return o.reshape(b, l, d)
 
 
-def attention(x, wqkv, bqkv, wp, bp, heads: int):
-    """components/attention.py:43-87 (tensor_par_size == 1, eval / dropout 0)."""
+def attention(x, wqkv, bqkv, wp, bp, heads: int, pmask=None, omask=None):
+    """components/attention.py:43-87 (tensor_par_size == 1).  Train-mode dropouts enter as explicit multipliers:
+    pmask on the probabilities (attn_drop), omask on the projected output (proj_drop, :82)."""
     b, n, c = x.shape
     hd = c // heads
     qkv = (x @ wqkv.t() + bqkv).reshape(b, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
-    o = mha_core(qkv[0], qkv[1], qkv[2], hd ** -0.5).transpose(1, 2).reshape(b, n, c)
-    return o @ wp.t() + bp
+    o = mha_core(qkv[0], qkv[1], qkv[2], hd ** -0.5, pmask).transpose(1, 2).reshape(b, n, c)
+    o = o @ wp.t() + bp
+    return o if omask is None else o * omask
 
 
-def mlp(x, w1, b1, w2, b2):
-    """components/mlp.py:57-73: fc1 -> GELU (erf) -> fc2 (dropout 0)."""
-    return F.gelu(x @ w1.t() + b1) @ w2.t() + b2
+def mlp(x, w1, b1, w2, b2, m1=None, m2=None):
+    """components/mlp.py:57-73: fc1 -> GELU (erf) -> drop1 -> fc2 -> drop2 (masks m1 / m2 as multipliers, None = off)."""
+    h = F.gelu(x @ w1.t() + b1)
+    if m1 is not None:
+        h = h * m1
+    o = h @ w2.t() + b2
+    return o if m2 is None else o * m2
 
 
-def block(x, sd: Dict[str, torch.Tensor], pre: str, heads: int):
-    """components/vit_blocks.py:76-81 with ls*/drop_path* = Identity (eval, init_values=None)."""
+def block(x, sd: Dict[str, torch.Tensor], pre: str, heads: int, masks: Optional[Dict[str, torch.Tensor]] = None):
+    """components/vit_blocks.py:76-81 with ls* = Identity (init_values=None).  masks (train mode, optional): multipliers
+    `attn` [B,H,N,N], `proj` [B,N,D], `fc1` [B,N,4D], `fc2` [B,N,D] and the per-sample DropPath scales `dp1`, `dp2` [B]."""
+    mk = masks or {}
     d = x.shape[-1]
     h = F.layer_norm(x, (d,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
-    x = x + attention(h, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"],
-                      sd[pre + "attn.proj.weight"], sd[pre + "attn.proj.bias"], heads)
+    a = attention(h, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"],
+                  sd[pre + "attn.proj.weight"], sd[pre + "attn.proj.bias"], heads, mk.get("attn"), mk.get("proj"))
+    if "dp1" in mk:
+        a = a * mk["dp1"].view(-1, 1, 1)
+    x = x + a
     h = F.layer_norm(x, (d,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
-    return x + mlp(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"],
-                   sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    m = mlp(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"],
+            sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"], mk.get("fc1"), mk.get("fc2"))
+    if "dp2" in mk:
+        m = m * mk["dp2"].view(-1, 1, 1)
+    return x + m
 
 
 def unpatchify(x, img_size, patch: int, scaling: int, out_channels: int):
@@ -212,8 +230,9 @@ def init_state_dict(cfg: Config, n_in: int, seed: int = 0, init_grid=None, fast:
 
 
 def forward(sd: Dict[str, torch.Tensor], cfg: Config, x: torch.Tensor, in_variables: List[str],
-            out_variables: List[str]) -> torch.Tensor:
-    """res_slimvit.py:312-338 (forward) with :245-299 (forward_encoder), eval mode."""
+            out_variables: List[str], masks: Optional[Dict] = None) -> torch.Tensor:
+    """res_slimvit.py:312-338 (forward) with :245-299 (forward_encoder).  Eval mode unless `masks` supplies the
+    train-mode dropout / DropPath multipliers ({"pos": [B,L,D], "blocks.i": {...}}, see block())."""
     if x.dim() == 5:
         x = x.flatten(1, 2)
     p, d = cfg.patch_size, cfg.embed_dim
@@ -232,8 +251,10 @@ def forward(sd: Dict[str, torch.Tensor], cfg: Config, x: torch.Tensor, in_variab
     t = t + pos_embed_for_grid(sd["pos_embed"], p, cfg.img_size)
     res_km = torch.tensor([float(cfg.spatial_resolution)], dtype=t.dtype)
     t = t + (sd["spatial_embed.weight"] @ res_km + sd["spatial_embed.bias"]).view(1, 1, d)
+    if masks is not None and "pos" in masks:          # pos_drop (res_slimvit.py:284)
+        t = t * masks["pos"]
     for i in range(cfg.depth):
-        t = block(t, sd, "blocks.%d." % i, cfg.num_heads)
+        t = block(t, sd, "blocks.%d." % i, cfg.num_heads, None if masks is None else masks.get("blocks.%d" % i))
     t = F.layer_norm(t, (d,), sd["norm.weight"], sd["norm.bias"], 1e-5)
     # decoder head                                          (res_slimvit.py:115-120,326)
     for i in range(cfg.decoder_depth):
@@ -462,9 +483,9 @@ LOSSES = {"mse": mse, "bayesian_tv": bayesian_tv}
 
 
 def training_loss(sd, cfg, x, y, in_variables, out_variables, loss_name="bayesian_tv", var_weights=None,
-                  lat=None, lpips_sd=None):
+                  lat=None, lpips_sd=None, masks=None):
     """training_step (:281-306): forward, clip, crop, loss (aggregate)."""
-    pred = forward(sd, cfg, x, in_variables, out_variables)
+    pred = forward(sd, cfg, x, in_variables, out_variables, masks)
     yhat = clip_replace_constant(y, pred, out_variables)
     tgt = crop_target(y, yhat)
     if loss_name == "perceptual":
