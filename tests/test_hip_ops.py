@@ -436,3 +436,30 @@ def test_colsum_batchsum(hip):
     o2 = torch.empty(40, 64, device="cuda")
     hip.batch_sum(bf(xb).cuda(), 3, 40, 64, o2)
     assert nerr(o2, xb.sum(0)) < 1e-6
+
+
+def test_bad_arguments_are_refused_not_run(hip):
+    """the ABI validates shapes on the host and returns an error code (wrapped as HipBackendError); nothing is launched"""
+    from climate_learn._hip import HipBackendError
+    x = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(HipBackendError):                       # head dim 96 is not built (-3 unsupported)
+        hip.attn_fwd(torch.zeros(1, 64, 3 * 2 * 96, dtype=torch.bfloat16, device="cuda"), 1, 64, 2, 96, 0.0, 0)
+    with pytest.raises(HipBackendError):                       # dropout probability out of range
+        hip.attn_fwd(torch.zeros(1, 64, 3 * 2 * 64, dtype=torch.bfloat16, device="cuda"), 1, 64, 2, 64, 1.0, 0)
+    out = torch.zeros(64, 100, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(HipBackendError):                       # N % 8 != 0
+        hip.gemm(x, torch.zeros(100, 96, dtype=torch.bfloat16, device="cuda"), out, 64, 100, 96, 96, 96, 100)
+    with pytest.raises(HipBackendError):                       # K-contiguous operand with K % 8 != 0
+        hip.gemm(torch.zeros(64, 100, dtype=torch.bfloat16, device="cuda"), torch.zeros(64, 100, dtype=torch.bfloat16, device="cuda"),
+                 torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda"), 64, 64, 100, 100, 100, 64)
+    with pytest.raises(HipBackendError):                       # LayerNorm width not a multiple of 8
+        hip.layernorm_fwd(torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda"), torch.zeros(100, dtype=torch.bfloat16, device="cuda"),
+                          torch.zeros(100, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(HipBackendError):                       # operands must live on the GPU: there is no CPU path
+        hip.layernorm_fwd(torch.zeros(4, 96, dtype=torch.bfloat16), torch.zeros(96, dtype=torch.bfloat16).cuda(),
+                          torch.zeros(96, dtype=torch.bfloat16).cuda())
+    with pytest.raises(HipBackendError):                       # wrong dtype
+        hip.attn_fwd(torch.zeros(1, 64, 3 * 2 * 64, dtype=torch.float32, device="cuda"), 1, 64, 2, 64, 0.0, 0)
+    with pytest.raises(HipBackendError):                       # more problems than one grouped launch takes
+        hip.gemm_grouped([])
+    torch.cuda.synchronize()                                   # nothing faulted
