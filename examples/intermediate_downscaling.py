@@ -6,7 +6,9 @@ model / data, reference configs/interm_*.yaml), same environment contract (SLURM
 SLURM_LOCALID / HOSTNAME, with a torchrun-style RANK / WORLD_SIZE / LOCAL_RANK fallback), same per-step prints
 and the same checkpoint dictionary keys and paths (reference :775-795).  Differences by decision:
   * the data-parallel engine is climate_learn.HipDataParallel (the FSDP NO_SHARD + bf16 MixedPrecision
-    equivalent); fsdp / tensor_par / seq_par degrees other than 1 are rejected (out of the hot-path scope);
+    equivalent); `fsdp > 1` selects its sharded-optimizer mode, `tensor_par > 1` the head-split tensor-parallel
+    blocks (climate_learn.dist.tp) with the reference's rank layout (tensor-parallel ranks adjacent) and per-rank
+    checkpoint files `<ckpt>_rank_<r>`; seq_par must be 1 as in the reference;
   * the bf16 branch uses HipGradScaler(init_scale=8192, growth_interval=100, min_scale=128) -- the behaviour
     the reference intends at :493-497 (where it raises NameError);
   * data comes from the synthetic IterDataModule (the npz data plane is SURVEY 8f-1).
@@ -37,15 +39,32 @@ def seed_everything(seed, rank=0):
     cl.manual_seed(seed, rank)
 
 
-def init_par_groups(world_rank, data_par_size, tensor_par_size, seq_par_size, fsdp_size, simple_ddp_size, world_size):
-    """Reference :161-262.  Only the pure data-parallel layout is accepted."""
+def init_par_groups(world_rank, data_par_size, tensor_par_size, seq_par_size, fsdp_size, simple_ddp_size, world_size,
+                    num_heads=None):
+    """Reference :161-262.  Rank layout: tensor-parallel ranks are adjacent (fastest varying), data-parallel ranks
+    stride by tensor_par_size.  Returns (data_par_group, tensor_par_group); every rank creates every group, in the
+    same order.  The fsdp / simple_ddp split of the data-parallel ranks needs no groups of its own here: `fsdp > 1`
+    selects the sharded-optimizer engine over the whole data-parallel group."""
     assert seq_par_size == 1, "Sequence parallelism not implemented"
-    assert tensor_par_size == 1, "tensor parallelism is outside the MI355X hot-path build"
-    assert fsdp_size == 1, "sharded FSDP is SURVEY 8f-4 (next); use simple_ddp"
     assert data_par_size * seq_par_size * tensor_par_size == world_size, \
         "DATA_PAR_SIZE * SEQ_PAR_SIZE * TENSOR_PAR_SIZE must equal to world_size"
-    group = dist.new_group(list(range(world_size))) if world_size > 1 else None
-    return group
+    if num_heads is not None:
+        assert num_heads % tensor_par_size == 0, "model heads % tensor parallel size must be 0"
+    if world_size == 1:
+        return None, None
+    tensor_par_group = data_par_group = None
+    if tensor_par_size > 1:
+        for i in range(data_par_size):
+            ranks = list(range(i * tensor_par_size, (i + 1) * tensor_par_size))
+            group = dist.new_group(ranks)
+            if world_rank in ranks:
+                tensor_par_group = group
+    for i in range(tensor_par_size):
+        ranks = [i + j * tensor_par_size for j in range(data_par_size)]
+        group = dist.new_group(ranks)
+        if world_rank in ranks:
+            data_par_group = group
+    return data_par_group, tensor_par_group
 
 
 def load_checkpoint(model, path, rank):
@@ -76,18 +95,22 @@ def main():
     div, overlap = (tiling.get("div", 1), tiling.get("overlap", 0)) if tiling.get("do_tiling", False) else (1, 0)
     fsdp_size, ddp_size = par.get("fsdp", 1), par.get("simple_ddp", 1)
     tp, sp = par.get("tensor_par", 1), par.get("seq_par", 1)
-    dp_group = init_par_groups(world_rank, fsdp_size * ddp_size, tp, sp, fsdp_size, ddp_size, world_size)
+    dp_size = fsdp_size * ddp_size
+    dp_group, tp_group = init_par_groups(world_rank, dp_size, tp, sp, fsdp_size, ddp_size, world_size, mc["num_heads"])
+    dp_rank, tp_rank = world_rank // tp, world_rank % tp
 
-    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0) if data_type == "bfloat16" else None
+    # a tensor-parallel rank that overflows in ITS weight shard must make every rank skip the step: sync_world
+    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0,
+                              sync_world=tp > 1) if data_type == "bfloat16" else None
     model = eng = optimizer = scheduler = None
     epoch_start = 0
-    seed_everything(0, world_rank)
+    seed_everything(0, dp_rank)       # the ranks of one tensor-parallel group share data and dropout seeds
     for data_key in dc["low_res_dir"]:
         in_vars, out_vars = dc["dict_in_variables"][data_key], dc["dict_out_variables"][data_key]
         syn = (dc.get("synthetic") or {}).get(data_key, {})
         dm = cl.data.IterDataModule(
             "downscaling", dc["low_res_dir"][data_key], dc["high_res_dir"][data_key], in_vars, out_vars=out_vars,
-            data_par_size=world_size, data_par_group=dp_group, subsample=1, batch_size=batch_size,
+            data_par_size=dp_size, data_par_group=dp_group, subsample=1, batch_size=batch_size,
             buffer_size=tr.get("buffer_size", 0), num_workers=tr.get("num_workers", 0), div=div, overlap=overlap,
             lowres_hw=tuple(syn.get("lowres_hw", (32, 64))), highres_hw=tuple(syn["highres_hw"]) if "highres_hw" in syn else None,
             steps_per_epoch=syn.get("steps_per_epoch", 4))
@@ -101,19 +124,22 @@ def main():
                                   "embed_dim": mc["embed_dim"], "depth": mc["depth"],
                                   "decoder_depth": mc["decoder_depth"], "num_heads": mc["num_heads"],
                                   "mlp_ratio": mc["mlp_ratio"], "drop_path": mc["drop_path"],
-                                  "drop_rate": mc["drop_rate"], "tensor_par_size": 1, "tensor_par_group": None,
+                                  "drop_rate": mc["drop_rate"], "tensor_par_size": tp, "tensor_par_group": tp_group,
                                   "FusedAttn_option": FusedAttn.CK if data_type == "bfloat16" else FusedAttn.DEFAULT})
             model, train_loss = out[0], out[1]
             ck = None
-            if tr.get("checkpoint") and os.path.exists(str(tr["checkpoint"])):
-                ck = load_checkpoint(model, tr["checkpoint"], world_rank)
+            suffix = "_rank_" + str(tp_rank) if tp > 1 else ""      # per tensor-parallel rank files (reference :52,:72)
+            if tr.get("checkpoint") and os.path.exists(str(tr["checkpoint"]) + suffix):
+                ck = load_checkpoint(model, str(tr["checkpoint"]) + suffix, world_rank)
             elif tr.get("pretrain"):       # shape-tolerant partial load (reference :70-80, :116-153)
                 if world_rank == 0:
                     print("load pretrained model", tr["pretrain"], flush=True)
-                cl.utils.load_pretrained_weights(model, str(tr["pretrain"]), verbose=world_rank == 0)
+                cl.utils.load_pretrained_weights(model, str(tr["pretrain"]) + suffix, verbose=world_rank == 0)
+            elif tp > 1:                   # from scratch: replicated weights come from the group's first rank (:83-112)
+                cl.dist.tp.sync_replicated(model, tp_group)
             # parallelism.fsdp > 1 asks the reference for sharded FSDP (HYBRID/FULL_SHARD, :583-617); here it selects the
             # sharded-optimizer engine (reduce-scatter + AdamW on 1/N + all-gather) over the whole data-parallel group
-            shard = fsdp_size > 1 and world_size > 1
+            shard = fsdp_size > 1 and dp_size > 1
             print("enter sharded optimizer (SHARD_GRAD_OP-like)," if shard else "enter NO SHARD only,", flush=True)
             eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
                                      sync_module_states=True, shard_optimizer=shard)
@@ -162,11 +188,14 @@ def main():
             scheduler.step()
             if world_rank == 0:
                 print("epoch: ", epoch, " epoch_loss ", float(epoch_loss), flush=True)
+            model_states, optimizer_states = eng.state_dict(), optimizer.state_dict()     # collective when sharded
+            if world_rank < tp:            # one file per tensor-parallel rank of the first group (reference :778-790)
                 os.makedirs("checkpoints/climate", exist_ok=True)
-                torch.save({"epoch": epoch, "model_state_dict": eng.state_dict(),
-                            "optimizer_state_dict": optimizer.state_dict(),
+                torch.save({"epoch": epoch, "model_state_dict": model_states,
+                            "optimizer_state_dict": optimizer_states,
                             "scheduler_state_dict": scheduler.state_dict()},
-                           "checkpoints/climate/interm_epoch_" + str(epoch) + ".ckpt")
+                           "checkpoints/climate/interm_epoch_" + str(epoch) + ".ckpt" + suffix)
+            del model_states, optimizer_states
             if world_size > 1:
                 dist.barrier()
     if world_size > 1:

@@ -98,6 +98,11 @@ int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, cons
 /* dym = dy * dropmask * rowscale (backward of the dropout/DropPath epilogue); dym may alias dy */
 int orbit2_dropout_bwd(const void* dy, void* dym, int M, int N, float drop_p, uint64_t seed, const float* rowscale,
                        int rows_per_scale, void* stream);
+/* y = residual + rowscale[m/rows_per_scale] * dropout(x + addend[m % res_mod]) (bf16; every term optional): the part of
+ * the GEMM epilogue that has to wait for the all-reduce of tensor-parallel partial products (row-parallel proj / fc2,
+ * reference attention.py:81-85, mlp.py:66-71).  Same mask hash as the epilogue; y may alias x. */
+int orbit2_post_reduce(const void* x, const void* addend, int res_mod, const void* residual, void* y, int M, int N,
+                       float drop_p, uint64_t seed, const float* rowscale, int rows_per_scale, void* stream);
 /* out[N] = beta*out + sum_m x[m][n]  (bias gradients; sum over batch).  ws: fp32 >= colsum_ws_floats */
 int orbit2_colsum(const void* x, int x_fp32, int M, int N, int ldx, void* out, int out_fp32, float beta, float* ws,
                   int ws_floats, void* stream);

@@ -264,6 +264,19 @@ def dropout_bwd(dy, M, N, drop_p, seed, rowscale=None, rows_per_scale=0, out=Non
     return out
 
 
+def post_reduce(x, M, N, addend=None, res_mod=0, residual=None, drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0,
+                out=None):
+    """y = residual + rowscale * dropout(x + addend[m % res_mod]); in place on x unless `out` is given"""
+    _dev(x, BF, "x")
+    for t, nm in ((addend, "addend"), (residual, "residual")):
+        if t is not None:
+            _dev(t, BF, nm)
+    out = x if out is None else out
+    _chk(lib().orbit2_post_reduce(_p(x), _p(addend), res_mod, _p(residual), _p(out), M, N, C.c_float(drop_p),
+                                  C.c_uint64(seed), _p(rowscale), rows_per_scale, _stream()), "orbit2_post_reduce")
+    return out
+
+
 def colsum(x, M, N, ldx, out, beta=0.0):
     if x.dtype not in (BF, F32):
         raise HipBackendError("colsum input must be bf16/fp32")

@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 
 from . import _hip
+from .dist import tp as _tp
 
 BF, F32 = torch.bfloat16, torch.float32
 
@@ -51,6 +52,12 @@ class _SeedStream:
 
 
 seeds = _SeedStream()
+
+
+def tp_seed(seed: int, tp_rank: int) -> int:
+    """The ranks of a tensor-parallel group share one seed stream (replicated activations get identical masks);
+    attention-probability dropout acts on DIFFERENT heads on each rank, so its seed is decorrelated here."""
+    return (seed ^ (tp_rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
 
 
 def manual_seed(seed: int, rank: int = 0):
@@ -177,14 +184,16 @@ class BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2):
         B, L, D = x.shape
-        H = cfg["heads"]
-        d = D // H
+        grp = cfg.get("tp_group")
+        tp = _tp.group_size(grp)
+        H = cfg["heads"] // tp                     # heads / hidden units held by this tensor-parallel rank
+        d = D // cfg["heads"]
         M = B * L
         hid = w1.shape[0]
         p_attn, p_proj, p_mlp, p_path = cfg["attn_drop"], cfg["proj_drop"], cfg["mlp_drop"], cfg["drop_path"]
-        sa = seeds.next() if p_attn > 0 else 0
+        sa = tp_seed(seeds.next(), _tp.group_rank(grp)) if p_attn > 0 else 0
         sp = seeds.next() if p_proj > 0 else 0
-        s1 = seeds.next() if p_mlp > 0 else 0
+        s1 = tp_seed(seeds.next(), _tp.group_rank(grp)) if p_mlp > 0 else 0
         s2 = seeds.next() if p_mlp > 0 else 0
         dp1 = dp2 = None
         if p_path > 0:
@@ -192,10 +201,11 @@ class BlockFn(torch.autograd.Function):
             dp2 = _hip.droppath_scales(B, p_path, seeds.next(), x.device)
         x2d = x.reshape(M, D)
         saved = BlockFn._run(x2d, B, L, D, H, d, M, hid, (p_attn, p_proj, p_mlp), (sa, sp, s1, s2), dp1, dp2,
-                             (n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2))
+                             (n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2), grp)
         x2 = saved[-1]
         ctx.meta = (B, L, D, H, d, M, hid, (p_attn, p_proj, p_mlp), (sa, sp, s1, s2), cfg.get("recompute", False))
         ctx.params = (n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2)
+        ctx.grp = grp
         if ctx.meta[-1]:
             ctx.save_for_backward(x2d, dp1, dp2)
         else:
@@ -203,21 +213,34 @@ class BlockFn(torch.autograd.Function):
         return x2.view(B, L, D)
 
     @staticmethod
-    def _run(x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, prm):
+    def _run(x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, prm, grp=None):
         n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2 = prm
         p_attn, p_proj, p_mlp = ps
         sa, sp, s1, s2 = sds
+        Dl = H * d                                  # = D on one rank, D / tensor_par_size under head-split
         h1, mean1, rstd1 = _hip.layernorm_fwd(x2d, cw(n1w), cw(n1b))
-        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * D, D)
+        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * Dl, D)
         o, lse = _hip.attn_fwd(qkv, B, L, H, d, p_attn, sa)
-        o2d = o.view(M, D)
-        x1 = _linear_fwd(o2d, wp, bp, M, D, D, drop_p=p_proj, seed=sp, rowscale=dp1, rows_per_scale=L,
-                         residual=x2d, ldr=D)
+        o2d = o.view(M, Dl)
+        if grp is None:
+            x1 = _linear_fwd(o2d, wp, bp, M, D, Dl, drop_p=p_proj, seed=sp, rowscale=dp1, rows_per_scale=L,
+                             residual=x2d, ldr=D)
+        else:
+            # row-parallel proj: bias + dropout on the partial product (identical masks on all ranks of the group),
+            # SUM over the group, then DropPath scale + residual (reference attention.py:81-85, vit_blocks.py:77)
+            part = _linear_fwd(o2d, wp, bp, M, D, Dl, drop_p=p_proj, seed=sp)
+            _tp.all_reduce_sum(part, grp)
+            x1 = _hip.post_reduce(part, M, D, residual=x2d, rowscale=dp1, rows_per_scale=L)
         h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b))
         pre = torch.empty(M, hid, dtype=BF, device=x2d.device)
         hm = _linear_fwd(h2, w1, b1, M, hid, D, act=1, save_pre=pre, drop_p=p_mlp, seed=s1)
-        x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
-                         residual=x1, ldr=D)
+        if grp is None:
+            x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
+                             residual=x1, ldr=D)
+        else:
+            part = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2)
+            _tp.all_reduce_sum(part, grp)
+            x2 = _hip.post_reduce(part, M, D, residual=x1, rowscale=dp2, rows_per_scale=L)
         return h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm, x2
 
     @staticmethod
@@ -229,9 +252,10 @@ class BlockFn(torch.autograd.Function):
         if recompute:
             x2d, dp1, dp2 = ctx.saved_tensors
             h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm, _ = BlockFn._run(
-                x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, ctx.params)
+                x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, ctx.params, ctx.grp)
         else:
             x2d, dp1, dp2, h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm = ctx.saved_tensors
+        grp, Dl = ctx.grp, H * d
         dx2 = dx2.reshape(M, D)
         if dx2.dtype != BF or not dx2.is_contiguous():
             dx2 = dx2.contiguous().to(BF)
@@ -244,18 +268,20 @@ class BlockFn(torch.autograd.Function):
         i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D)
         dh2 = _dx(dpre, w1, M, hid, D)
         del dpre, h2
+        _tp.all_reduce_sum(dh2, grp)        # column-parallel fc1: the input gradient is a partial sum per rank
         dx1, gn2w, gn2b = _ln_bwd(dh2, x1, n2w, n2b, mean2, rstd2, dx2)
         del dh2, x1
         # ---- attention branch
         dym1 = _drop_bwd(dx1, M, D, p_proj, sp, dp1, L)
-        ip, gbp = dws.add(dym1, o2d, wp, bp, M, D, D)
-        do = _dx(dym1, wp, M, D, D)
+        ip, gbp = dws.add(dym1, o2d, wp, bp, M, D, Dl)
+        do = _dx(dym1, wp, M, D, Dl)
         del dym1
         dqkv = _hip.attn_bwd(qkv, o2d, do, lse, B, L, H, d, p_attn, sa)
         del do, o2d, qkv
-        iq, gbqkv = dws.add(dqkv, h1, wqkv, bqkv, M, 3 * D, D)
-        dh1 = _dx(dqkv, wqkv, M, 3 * D, D)
+        iq, gbqkv = dws.add(dqkv, h1, wqkv, bqkv, M, 3 * Dl, D)
+        dh1 = _dx(dqkv, wqkv, M, 3 * Dl, D)
         del dqkv, h1
+        _tp.all_reduce_sum(dh1, grp)        # column-parallel qkv
         dx, gn1w, gn1b = _ln_bwd(dh1, x2d, n1w, n1b, mean1, rstd1, dx1)
         gws = dws.flush()
         gw2, gw1, gwp, gwqkv = gws[i2], gws[i1], gws[ip], gws[iq]
@@ -395,10 +421,10 @@ class AttnCoreFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(d)) v on the packed qkv activation [B, L, 3*H*d] (attention.py:50-78)."""
 
     @staticmethod
-    def forward(ctx, qkv, H, p_drop):
+    def forward(ctx, qkv, H, p_drop, tp_rank=0):
         B, L, C3 = qkv.shape
         d = C3 // (3 * H)
-        s = seeds.next() if p_drop > 0 else 0
+        s = tp_seed(seeds.next(), tp_rank) if p_drop > 0 else 0
         q = qkv.contiguous()
         o, lse = _hip.attn_fwd(q, B, L, H, d, p_drop, s)
         ctx.meta = (B, L, H, d, p_drop, s)
@@ -410,7 +436,7 @@ class AttnCoreFn(torch.autograd.Function):
         B, L, H, d, p, s = ctx.meta
         q, o, lse = ctx.saved_tensors
         dq = _hip.attn_bwd(q, o, do.contiguous().to(BF), lse, B, L, H, d, p, s)
-        return dq, None, None
+        return dq, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -462,28 +488,35 @@ def sgemm(A, B, ta=False, tb=False):
 # ------------------------------------------------------------------------------------------------------
 class EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xgrid, stab, gtab, posres, wp, bp, H, p_drop):
+    def forward(ctx, xgrid, stab, gtab, posres, wp, bp, H, p_drop, grp=None):
+        """H = heads held by this rank; under head-split tensor parallelism wp is [D, D / tp] and the proj output is
+        summed over `grp` before the position / resolution embedding and the dropout are applied."""
         B, V, h, w = xgrid.shape
-        D = wp.shape[0]
+        D, Dl = wp.shape
         L = (h // 2) * (w // 2)
         M = B * L
         xg = xgrid.contiguous()
         if xg.dtype != F32:
             xg = xg.float()
         st, gt = stab.contiguous(), gtab.contiguous()
-        z, attw = _hip.varagg_fwd(xg, st, gt, H, D)
+        z, attw = _hip.varagg_fwd(xg, st, gt, H, Dl)
         pr16 = _hip.cast_to_bf16(posres.contiguous())
         s = seeds.next() if p_drop > 0 else 0
-        tok = _linear_fwd(z, wp, bp, M, D, D, drop_p=p_drop, seed=s, residual=pr16, ldr=D, res_mod=L,
-                          res_first=True)
-        ctx.meta = (B, V, h, w, H, D, L, M, p_drop, s)
+        if grp is None:
+            tok = _linear_fwd(z, wp, bp, M, D, Dl, drop_p=p_drop, seed=s, residual=pr16, ldr=D, res_mod=L,
+                              res_first=True)
+        else:
+            tok = _linear_fwd(z, wp, bp, M, D, Dl)          # row-parallel proj (attention.py:176-181)
+            _tp.all_reduce_sum(tok, grp)
+            _hip.post_reduce(tok, M, D, addend=pr16, res_mod=L, drop_p=p_drop, seed=s)
+        ctx.meta = (B, V, h, w, H, D, Dl, L, M, p_drop, s)
         ctx.prm = (wp, bp)
         ctx.save_for_backward(xg, gt, attw, z)
         return tok.view(B, L, D)
 
     @staticmethod
     def backward(ctx, dtok):
-        B, V, h, w, H, D, L, M, p, s = ctx.meta
+        B, V, h, w, H, D, Dl, L, M, p, s = ctx.meta
         wp, bp = ctx.prm
         xg, gt, attw, z = ctx.saved_tensors
         d2 = dtok.reshape(M, D)
@@ -494,10 +527,10 @@ class EmbedFn(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             dposres = torch.empty(L, D, dtype=F32, device=g.device)
             _hip.batch_sum(g, B, L, D, dposres)
-        gwp, gbp = _dw(g, z, wp, bp, M, D, D)
-        dz = _dx(g, wp, M, D, D)
-        dstab, dgtab = _hip.varagg_bwd(xg, gt, attw, dz, H, D)
-        return None, dstab, dgtab, dposres, gwp, gbp, None, None
+        gwp, gbp = _dw(g, z, wp, bp, M, D, Dl)
+        dz = _dx(g, wp, M, D, Dl)
+        dstab, dgtab = _hip.varagg_bwd(xg, gt, attw, dz, H, Dl)
+        return None, dstab, dgtab, dposres, gwp, gbp, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -26,6 +26,9 @@ SALT_STEP = 0x9E3779B97F4A7C15       # odd: the salt walks through all 2^64 valu
 class GraphedTrainStep:
     def __init__(self, engine, loss_metric, batch, var_weights, scaler=None, warmup: int = 2):
         x, y, self.in_vars, self.out_vars = batch
+        if getattr(engine.module, "tensor_par_size", 1) > 1:
+            raise NotImplementedError("GraphedTrainStep covers the data-parallel step; tensor-parallel steps (large "
+                                      "models, not launch-bound) run eagerly")
         self.engine, self.loss_metric, self.var_weights, self.scaler = engine, loss_metric, var_weights, scaler
         self.device = engine.device
         self.x = x.to(self.device).clone()           # static input buffers: refill with .copy_ between replays

@@ -27,16 +27,21 @@ class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, norm_layer=None,
                  bias=True, drop=0.0, use_conv=False, tensor_par_size: int = 1, tensor_par_group=None):
         super().__init__()
-        if tensor_par_size != 1:
-            raise NotImplementedError("tensor parallelism is outside the data-parallel hot path (SURVEY 2.1)")
         assert act_layer is nn.GELU and norm_layer is None and not use_conv
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1 = HipLinear(in_features, hidden_features, bias=bias)
-        self.fc2 = HipLinear(hidden_features, out_features, bias=bias)
+        assert hidden_features % tensor_par_size == 0
+        self.tensor_par_size, self.tensor_par_group = tensor_par_size, tensor_par_group
+        # hidden units are divided over the tensor-parallel ranks (reference mlp.py:50-55)
+        self.fc1 = HipLinear(in_features, hidden_features // tensor_par_size, bias=bias)
+        self.fc2 = HipLinear(hidden_features // tensor_par_size, out_features, bias=bias)
         self.drop = float(drop)
 
     def forward(self, x):
+        from ....dist import tp as _tp
         p = self.drop if self.training else 0.0
         cfg = {"ln": False, "p_mid": p, "p_out": p}
-        return _ops.ChainFn.apply(x, cfg, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        if self.tensor_par_size > 1:
+            x = _tp.IdentityFwdAllReduceBwd.apply(x, self.tensor_par_group)
+        y = _ops.ChainFn.apply(x, cfg, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        return _tp.AllReduceFwdIdentityBwd.apply(y, self.tensor_par_group) if self.tensor_par_size > 1 else y

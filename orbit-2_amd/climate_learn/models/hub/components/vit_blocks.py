@@ -49,6 +49,7 @@ class Block(nn.Module):
                        tensor_par_size=tensor_par_size, tensor_par_group=tensor_par_group)
         self.drop_path = float(drop_path)
         self.recompute = False
+        self.tensor_par_group = tensor_par_group if tensor_par_size > 1 else None
 
     def forward(self, x):
         tr = self.training
@@ -59,6 +60,7 @@ class Block(nn.Module):
             "mlp_drop": self.mlp.drop if tr else 0.0,
             "drop_path": self.drop_path if tr else 0.0,
             "recompute": self.recompute,
+            "tp_group": self.tensor_par_group,
         }
         a, m = self.attn, self.mlp
         return _ops.BlockFn.apply(x, cfg, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,

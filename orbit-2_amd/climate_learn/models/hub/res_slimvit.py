@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from ... import _ops
+from ...dist import tp as _tp
 from ...utils.fused_attn import FusedAttn
 from .components.attention import VariableMapping_Attention
 from .components.mlp import HipLinear
@@ -51,8 +52,12 @@ class Res_Slim_ViT(nn.Module):
                  decoder_depth=8, num_heads=16, mlp_ratio=4.0, tensor_par_size=1, tensor_par_group=None,
                  FusedAttn_option=FusedAttn.HIP):
         super().__init__()
-        if tensor_par_size != 1 or tensor_par_group is not None:
-            raise NotImplementedError("tensor_par_size must be 1: the build covers the data-parallel path only")
+        if tensor_par_size > 1:
+            if tensor_par_group is None or _tp.group_size(tensor_par_group) != tensor_par_size:
+                raise ValueError("tensor_par_size=%d needs a tensor_par_group of that many ranks" % tensor_par_size)
+            assert num_heads % tensor_par_size == 0, "model heads % tensor parallel size must be 0"
+        else:
+            tensor_par_group = None
         if patch_size != 2:
             raise NotImplementedError("the folded patch-embed kernel implements patch_size=2 (all interm_* configs)")
         self.default_vars = list(default_vars)
@@ -63,7 +68,7 @@ class Res_Slim_ViT(nn.Module):
         self.patch_size, self.history, self.embed_dim = patch_size, history, embed_dim
         self.num_heads, self.decoder_depth = num_heads, decoder_depth
         self.spatial_resolution = 0
-        self.tensor_par_size, self.tensor_par_group = 1, None
+        self.tensor_par_size, self.tensor_par_group = tensor_par_size, tensor_par_group
         D = embed_dim
 
         self.spatial_embed = HipLinear(1, D)
@@ -72,13 +77,15 @@ class Res_Slim_ViT(nn.Module):
         self.var_map = {v: i for i, v in enumerate(self.default_vars)}
         self.var_embed = nn.Parameter(torch.zeros(1, len(self.default_vars), D))
         self.var_query = nn.Parameter(torch.zeros(1, 1, D))
-        self.var_agg = VariableMapping_Attention(D, fused_attn=FusedAttn_option, num_heads=num_heads, qkv_bias=False)
+        self.var_agg = VariableMapping_Attention(D, fused_attn=FusedAttn_option, num_heads=num_heads, qkv_bias=False,
+                                                 tensor_par_size=tensor_par_size, tensor_par_group=tensor_par_group)
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, D), requires_grad=learn_pos_emb)
         self.pos_drop_p = float(drop_rate)
         rates = torch.linspace(0, drop_path, depth).tolist()
         self.blocks = nn.ModuleList([
             Block(D, num_heads=num_heads, fused_attn=FusedAttn_option, mlp_ratio=mlp_ratio, qkv_bias=True,
-                  drop_path=rates[i], proj_drop=drop_rate, attn_drop=drop_rate) for i in range(depth)])
+                  drop_path=rates[i], proj_drop=drop_rate, attn_drop=drop_rate, tensor_par_size=tensor_par_size,
+                  tensor_par_group=tensor_par_group) for i in range(depth)])
         self.norm = HipLayerNorm(D)
 
         s = superres_mag
@@ -95,6 +102,8 @@ class Res_Slim_ViT(nn.Module):
             p._o2_lowp = False
         self.initialize_weights()
         self._idx_cache = {}
+        if tensor_par_size > 1:
+            _tp.tag_sharded(self)
 
     # ------------------------------------------------------------------ init (res_slimvit.py:125-145)
     def initialize_weights(self):
@@ -134,19 +143,26 @@ class Res_Slim_ViT(nn.Module):
 
     def _tables(self, ids):
         """Score / value tables of the folded variable aggregation (fp32, autograd through the HIP sgemm)."""
-        D, H = self.embed_dim, self.num_heads
-        dh = D // H
-        wq, wkv = self.var_agg.q.weight, self.var_agg.kv.weight
-        qv = _ops.sgemm(self.var_query.view(1, D), wq, tb=True)                  # [1, D] = var_query Wq^T
-        qblk = torch.block_diag(*qv.view(H, 1, dh).unbind(0))                    # [H, D], head-block structure
-        u = _ops.sgemm(qblk, wkv[:D]) * (dh ** -0.5)                             # [H, D] = scale * q_h^T Wk_h
+        D, grp = self.embed_dim, self.tensor_par_group
+        dh = D // self.num_heads
+        H = self.num_heads // self.tensor_par_size       # heads of this tensor-parallel rank; Dl = H * dh columns
+        Dl = H * dh
+        wq, wkv = self.var_agg.q.weight, self.var_agg.kv.weight                  # [Dl, D], [2 Dl, D]
+        vq = self.var_query.view(1, D)
+        if grp is not None:    # replicated inputs of a head-split attention: their gradients are partial per rank
+            vq = _tp.IdentityFwdAllReduceBwd.apply(vq, grp)            # (attention.py:134-137)
+        qv = _ops.sgemm(vq, wq, tb=True)                                         # [1, Dl] = var_query Wq^T
+        qblk = torch.block_diag(*qv.view(H, 1, dh).unbind(0))                    # [H, Dl], head-block structure
+        u = _ops.sgemm(qblk, wkv[:Dl]) * (dh ** -0.5)                            # [H, D] = scale * q_h^T Wk_h
         rows = []
         for v in ids:
             te = self.token_embeds[v].proj
             rows.append(torch.cat([te.weight.view(D, 4).t(), (te.bias + self.var_embed[0, v]).view(1, D)], 0))
         cmat = torch.stack(rows).view(len(ids) * 5, D)                           # [(v,c), D]
+        if grp is not None:
+            cmat = _tp.IdentityFwdAllReduceBwd.apply(cmat, grp)
         stab = _ops.sgemm(u, cmat, tb=True).view(H, len(ids), 5)
-        gtab = _ops.sgemm(cmat, wkv[D:], tb=True).view(len(ids), 5, D)
+        gtab = _ops.sgemm(cmat, wkv[Dl:], tb=True).view(len(ids), 5, Dl)
         return stab, gtab
 
     def _posres(self):
@@ -160,7 +176,7 @@ class Res_Slim_ViT(nn.Module):
         stab, gtab = self._tables(ids)
         p = self.pos_drop_p if self.training else 0.0
         t = _ops.EmbedFn.apply(x, stab, gtab, self._posres(), self.var_agg.proj.weight, self.var_agg.proj.bias,
-                               self.num_heads, p)
+                               self.num_heads // self.tensor_par_size, p, self.tensor_par_group)
         for blk in self.blocks:
             t = blk(t)
         return t

@@ -13,6 +13,8 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from .dist import tp as _tp
+
 from . import _hip
 
 F32 = torch.float32
@@ -118,12 +120,13 @@ class HipGradScaler:
     """Dynamic loss scaling: scale(loss) -> backward -> step(optimizer) -> update()."""
 
     def __init__(self, init_scale=8192.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=100,
-                 min_scale=128.0, process_group=None):
+                 min_scale=128.0, process_group=None, sync_world=False):
         self._scale = float(init_scale)
         self.growth_factor, self.backoff_factor = growth_factor, backoff_factor
         self.growth_interval, self.min_scale = growth_interval, min_scale
         self._good = 0
         self.pg = process_group
+        self.sync_world = sync_world     # found_inf is agreed over ALL ranks (tensor-parallel shards differ per rank)
         self._found = None
 
     def get_scale(self):
@@ -140,7 +143,9 @@ class HipGradScaler:
         fi.zero_()
         for sg in eng.opt_segments:       # with a sharded optimizer: this rank's reduced chunk of every bf16 bucket
             _hip.check_finite((eng.g16 if sg["kind"] == "lo" else eng.g32)[sg["og"]:], sg["n"], fi)
-        if eng.world > 1:
+        if self.sync_world and dist.is_initialized() and dist.get_world_size() > 1:
+            _tp.all_reduce_max(fi, None)
+        elif eng.world > 1:
             dist.all_reduce(fi, op=dist.ReduceOp.MAX, group=eng.pg)
         optimizer.grad_scale = 1.0 / self._scale
         optimizer.check_inf = True

@@ -185,6 +185,55 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   }
 }
 
+// ---- what a GEMM epilogue does AFTER a cross-rank reduction of partial products -----------
+// y = residual + rowscale[m / rps] * dropout(x + addend[m % res_mod])   (every term optional; same mask hash and
+// order of operations as gemm.hip's epilogue, so a tensor-parallel block equals the single-rank fused one)
+__global__ __launch_bounds__(256) void post_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend,
+                                                          int res_mod, const bf16_t* __restrict__ residual,
+                                                          bf16_t* __restrict__ y, int M, int N, unsigned thr,
+                                                          float dscale, uint64_t seed,
+                                                          const float* __restrict__ rowscale, int rows_per_scale) {
+  const int64_t nch = (int64_t)M * N / 8;
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < nch; ch += (int64_t)gridDim.x * 256) {
+    const int64_t idx = ch * 8;
+    const int m = (int)(idx / N);
+    const int n = (int)(idx - (int64_t)m * N);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + idx);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f((bf16_t)(v[j] & 0xffff)); f[2 * j + 1] = bf2f((bf16_t)(v[j] >> 16)); }
+    if (addend) {
+      const int rm = res_mod > 0 ? (m % res_mod) : m;
+      const u32x4 a = *reinterpret_cast<const u32x4*>(addend + (size_t)rm * N + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[2 * j] += bf2f((bf16_t)(a[j] & 0xffff)); f[2 * j + 1] += bf2f((bf16_t)(a[j] >> 16)); }
+    }
+    if (thr) {
+      const uint64_t sd = seed ^ o2_seed_salt;
+      const uint32_t h0 = o2_hash64(sd, (uint64_t)idx >> 2), h1 = o2_hash64(sd, ((uint64_t)idx >> 2) + 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[j] = (((h0 >> (8 * j)) & 0xffu) >= thr) ? f[j] * dscale : 0.f;
+        f[4 + j] = (((h1 >> (8 * j)) & 0xffu) >= thr) ? f[4 + j] * dscale : 0.f;
+      }
+    }
+    if (rowscale) {
+      const float s = rowscale[m / rows_per_scale];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= s;
+    }
+    if (residual) {
+      const u32x4 r = *reinterpret_cast<const u32x4*>(residual + idx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[2 * j] += bf2f((bf16_t)(r[j] & 0xffff)); f[2 * j + 1] += bf2f((bf16_t)(r[j] >> 16)); }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+    *reinterpret_cast<u32x4*>(y + idx) = o;
+  }
+}
+
 // ---- dropout backward ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dym,
                                                           int M, int N, unsigned thr, float dscale, uint64_t seed,
@@ -481,6 +530,19 @@ extern "C" int orbit2_dropout_bwd(const void* dy, void* dym, int M, int N, float
   hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((int64_t)M * N / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy, (bf16_t*)dym, M, N, thr, 256.0f / (256.0f - (float)thr), seed, rowscale,
                      rows_per_scale);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_post_reduce(const void* x, const void* addend, int res_mod, const void* residual, void* y, int M,
+                                  int N, float drop_p, uint64_t seed, const float* rowscale, int rows_per_scale,
+                                  void* stream) {
+  if (!x || !y || M <= 0 || N <= 0 || (N & 7) || drop_p < 0.f || drop_p >= 1.f || res_mod < 0) return O2_ERR_ARG;
+  if (rowscale && rows_per_scale <= 0) return O2_ERR_ARG;
+  const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
+  hipLaunchKernelGGL(post_reduce_kernel, dim3(grid_for((int64_t)M * N / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)addend, res_mod, (const bf16_t*)residual, (bf16_t*)y, M, N, thr,
+                     256.0f / (256.0f - (float)thr), seed, rowscale, rows_per_scale);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

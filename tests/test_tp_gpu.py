@@ -1,0 +1,206 @@
+"""Head-split tensor parallelism (climate_learn.dist.tp) on the GPU: two ranks of ONE tensor-parallel
+group run as two processes on the box's single card (gloo rendezvous; the collective stages through host memory,
+RCCL refuses two ranks on one device).  Each rank loads ITS slice of the reference's golden tensor_par_size=1
+weights and the pair must reproduce the reference's prediction and gradients (tests/golden/model_*_hd64.npz) and
+the single-rank HIP model's to bf16 rounding."""
+import os
+import socket
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _nerr(a, b):
+    a, b = a.detach().float().cpu().double(), torch.as_tensor(b).detach().float().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().float().cpu().double(), torch.as_tensor(b).detach().float().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _build(c, tp, grp):
+    from climate_learn.models.hub import Res_Slim_ViT
+    m = Res_Slim_ViT(c.get("default_vars", c["in_vars"]), c["grid"], len(c["in_vars"]), len(c["out_vars"]), 1,
+                     patch_size=2, embed_dim=c["D"], depth=c["depth"], decoder_depth=c["dd"], num_heads=c["heads"],
+                     drop_path=0.1, drop_rate=0.1, learn_pos_emb=True, tensor_par_size=tp, tensor_par_group=grp)
+    m.data_config(156.0, c["grid"], len(c["in_vars"]), len(c["out_vars"]))
+    return m
+
+
+def _parity_worker(rank, world, port, tag, q):
+    try:
+        import sys
+        sys.path.insert(0, HERE)
+        from test_model_gpu import CASES, VW
+        from climate_learn.dist import tp
+        from climate_learn.metrics import Bayesian_TV
+        from climate_learn.trainer import clip_replace_constant
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        grp = dist.new_group(list(range(world)))
+        c = CASES[tag]
+        z = np.load(os.path.join(GOLDEN, "model_%s.npz" % tag))
+        full = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+        # the golden biases of the row-parallel Linears are the reference's (non-zero): rank 0 carries them
+        mine = tp.shard_state_dict(full, world, rank, c["heads"])
+        assert mine["blocks.0.attn.qkv.weight"].shape == (3 * c["D"] // world, c["D"])
+        assert mine["blocks.0.mlp.fc2.weight"].shape[1] == full["blocks.0.mlp.fc2.weight"].shape[1] // world
+        m = _build(c, world, grp)
+        m.load_state_dict(mine, strict=True)
+        m = m.cuda().eval()
+        x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+
+        def run(model):
+            pred = model(x, c["in_vars"], c["out_vars"])
+            raw = pred.detach().clone()                      # clip_replace_constant clamps in place
+            yhat = clip_replace_constant(y, pred, c["out_vars"])
+            loss = Bayesian_TV(aggregate_only=False)(yhat, y, var_names=c["out_vars"], var_weights=VW)
+            loss[-1].backward()
+            return raw, loss
+
+        pred, loss = run(m)
+        # (a) the reference's own tensor_par_size=1 result
+        assert _nerr(pred, z["pred"]) < 2e-2, _nerr(pred, z["pred"])
+        assert _nerr(loss, z["loss.bayesian_tv"]) < 1e-2, _nerr(loss, z["loss.bayesian_tv"])
+        # (b) the single-rank HIP model on the same weights (both ranks compute it; the card is shared)
+        ref = _build(c, 1, None)
+        ref.load_state_dict(full, strict=True)
+        ref = ref.cuda().eval()
+        pred1, _ = run(ref)
+        assert _nerr(pred, pred1) < 5e-3, _nerr(pred, pred1)
+        g1 = dict(ref.named_parameters())
+        worst = []
+        for n, p in m.named_parameters():
+            want = g1[n].grad
+            if want is None:           # a default variable this dataset does not feed
+                assert p.grad is None, n
+                continue
+            assert p.grad is not None, n
+            kind = tp.split_kind(n)
+            if kind is not None:
+                want = tp._cut(want, kind, world, rank, c["heads"])
+            assert want.shape == p.grad.shape, n
+            e = _rel_l2(p.grad, want)
+            worst.append((e, n))
+            k = "g.bayesian_tv." + n
+            if k in z.files:           # and against the reference's gradient of the same slice
+                gz = torch.from_numpy(z[k])
+                gz = tp._cut(gz, kind, world, rank, c["heads"]) if kind is not None else gz
+                assert _rel_l2(p.grad, gz) < 6e-2, (n, _rel_l2(p.grad, gz))
+        worst.sort(reverse=True)
+        assert worst[0][0] < 5e-2, worst[:5]      # bf16 rounding differs (partial products are rounded before the sum)
+        # merging the two ranks' dicts gives back the full dict (summed biases included)
+        shards = [None] * world
+        dist.all_gather_object(shards, {k: v.cpu() for k, v in m.state_dict().items()}, group=grp)
+        merged = tp.merge_state_dicts(shards, c["heads"])
+        for k, v in full.items():
+            assert torch.equal(merged[k], v), k
+        q.put((rank, "ok", worst[:3]))
+    except Exception:
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _spawn(fn, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, 2, port) + args + (q,)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert r[1] == "ok", "rank %d:\n%s" % (r[0], r[2])
+    return res
+
+
+@pytest.mark.parametrize("tag", ["v5c1_hd64", "v7c3_hd64"])
+def test_tp2_matches_reference_golden_and_single_rank(tag):
+    print(_spawn(_parity_worker, tag))
+
+
+def _train_worker(rank, world, port, q):
+    """three optimizer steps in TRAIN mode (dropout + DropPath on, loss scaling, engine-managed gradients, block
+    recompute): loss finite and identical on both ranks, replicated parameters stay identical, shards differ"""
+    try:
+        import sys
+        sys.path.insert(0, HERE)
+        from test_model_gpu import CASES, VW
+        import climate_learn as cl
+        from climate_learn.dist import tp
+        from climate_learn.metrics import Bayesian_TV
+        from climate_learn.models.hub.components.vit_blocks import Block
+        from climate_learn.trainer import clip_replace_constant
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        grp = dist.new_group(list(range(world)))
+        dp = [dist.new_group([r]) for r in range(world)][rank]       # data-parallel degree 1
+        c = CASES["v7c3_hd64"]
+        torch.manual_seed(100 + rank)                                # DIFFERENT init per rank: sync must repair it
+        m = _build(c, world, grp).cuda()
+        tp.sync_replicated(m, grp)
+        cl.manual_seed(0, 0)                                         # seeded by data-parallel rank: same on both
+        eng = cl.HipDataParallel(m, process_group=dp, unit_types=(Block, torch.nn.Sequential),
+                                 sync_module_states=True)
+        m.blocks[0].recompute = True
+        opt = cl.load_optimizer(eng, "adamw", {"lr": 1e-3, "weight_decay": 1e-5, "betas": (0.9, 0.99)})
+        scaler = cl.HipGradScaler(init_scale=1024.0, sync_world=True)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, len(c["in_vars"]), *c["grid"], generator=g).cuda()
+        y = torch.randn(2, len(c["out_vars"]), c["grid"][0] * 4, c["grid"][1] * 4, generator=g).cuda()
+        eng.train()
+        lossf = Bayesian_TV(aggregate_only=True)
+        losses = []
+        for _ in range(3):
+            pred = eng(x, c["in_vars"], c["out_vars"])
+            loss = lossf(clip_replace_constant(y, pred, c["out_vars"]), y, var_names=c["out_vars"], var_weights=VW)
+            opt.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            assert not scaler.update()
+            losses.append(float(loss))
+        assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+        sds = [None] * world
+        dist.all_gather_object(sds, ({k: v.cpu() for k, v in eng.state_dict().items()}, losses), group=grp)
+        (a, la), (b, lb) = sds
+        assert la == lb, (la, lb)
+        for k in a:
+            same = torch.equal(a[k], b[k])
+            if tp.split_kind(k) is None:
+                # replicated tensors: identical up to the order of the var-agg backward's atomic adds
+                assert same or _rel_l2(a[k], b[k]) < 1e-4, k
+            else:
+                assert not same, k
+        q.put((rank, "ok", losses))
+    except Exception:
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_tp2_train_steps_keep_replicas_in_sync():
+    print(_spawn(_train_worker))
