@@ -61,6 +61,9 @@ def parse():
                     help="replay zero_grad+forward+loss+backward (+bucket all-reduces) from one captured hipGraph "
                          "(launch-bound small configurations); the roofline fields then come from an eager "
                          "instrumented pass")
+    ap.add_argument("--tensor-par", type=int, default=1,
+                    help="head-split tensor parallelism over adjacent ranks (DESIGN 5c); WORLD_SIZE = dp x tp, the "
+                         "reported value counts dp x batch samples per step")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter gradients, AdamW on 1/N of every unit, all-gather the bf16 copies")
     return ap.parse_args()
@@ -141,19 +144,35 @@ def main():
     V, C, B = len(in_vars), len(OUT_VARS), a.batch
     L = h * w // 4
     drop = 0.0 if a.no_dropout else 0.1
+    tp = a.tensor_par
+    if tp > 1 and (world % tp or a.graph):
+        raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)
+    dp_world, dp_rank = world // tp, rank // tp
+    dp_group = tp_group = None
+    if tp > 1:       # reference rank layout (examples/intermediate_downscaling.py:173-247): tp ranks adjacent
+        for i in range(dp_world):
+            g_ = dist.new_group(list(range(i * tp, (i + 1) * tp)))
+            tp_group = g_ if rank // tp == i else tp_group
+        for i in range(tp):
+            g_ = dist.new_group([i + j * tp for j in range(dp_world)])
+            dp_group = g_ if rank % tp == i else dp_group
     torch.manual_seed(0)
-    cl.manual_seed(0, rank)
+    cl.manual_seed(0, dp_rank)
     with torch.device(dev):
         model = Res_Slim_ViT(in_vars, (h, w), V, C, 1, superres_mag=4, cnn_ratio=4, patch_size=2, drop_path=drop,
                              drop_rate=drop, learn_pos_emb=True, embed_dim=m["embed_dim"], depth=m["depth"],
-                             decoder_depth=4, num_heads=m["num_heads"], mlp_ratio=4, FusedAttn_option=cl.FusedAttn.HIP)
+                             decoder_depth=4, num_heads=m["num_heads"], mlp_ratio=4, FusedAttn_option=cl.FusedAttn.HIP,
+                             tensor_par_size=tp, tensor_par_group=tp_group)
+    if tp > 1:
+        cl.dist.tp.sync_replicated(model, tp_group)
     model.data_config(156.0, (h, w), V, C)
     for blk in model.blocks:
         blk.recompute = a.recompute
     nparams = sum(p.numel() for p in model.parameters())
-    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential), shard_optimizer=a.shard_optimizer)
+    eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
+                             shard_optimizer=a.shard_optimizer, replica_group=tp_group)
     opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
-    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0)
+    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0, sync_world=tp > 1)
     loss_fn = Bayesian_TV(aggregate_only=True)
     if a.daymet:
         import warnings
@@ -163,7 +182,7 @@ def main():
     eng.train()
 
     # synthetic ERA5-shaped batch, resident in HBM before the timed region (SURVEY 8d input recipe)
-    g = torch.Generator().manual_seed(1000 + rank)
+    g = torch.Generator().manual_seed(1000 + dp_rank)
     x = torch.randn(B, V, h, w, generator=g)
     gc = torch.Generator().manual_seed(7)
     for i in range(4):
@@ -234,7 +253,7 @@ def main():
     loss_val = float(last.detach())
 
     if rank == 0:
-        sps = world * B * a.steps / dt
+        sps = dp_world * B * a.steps / dt
         f_dense = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"])
         f_exec = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"], folded_varagg=True)
         gm = prof.get("gemm_bf16", {"work": 0.0, "ms": 1.0, "launches": 0})
@@ -256,8 +275,8 @@ def main():
                                    % (a.model, "Daymet-like multi-variable" if a.daymet else "ERA5 1.40625deg->0.25deg",
                                       B, V, h, w, B, C, 4 * h, 4 * w, hy, wy,
                                       "perceptual (L1 + 0.5 LPIPS-VGG16)" if a.daymet else "bayesian_tv", drop, drop),
-                       "per_gpu_batch": B, "global_batch": B * world, "tokens_per_sample": L, "params": nparams,
-                       "parallelism": "dp%d" % world, "activation_recompute": bool(a.recompute),
+                       "per_gpu_batch": B, "global_batch": B * dp_world, "tokens_per_sample": L, "params": nparams,
+                       "parallelism": ("dp%d" % world) if tp == 1 else "dp%dxtp%d" % (dp_world, tp), "activation_recompute": bool(a.recompute),
                        "hipgraph": bool(a.graph),
                        "loss": "perceptual" if a.daymet else "bayesian_tv", "in_vars": V},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

@@ -142,7 +142,7 @@ def main():
             shard = fsdp_size > 1 and dp_size > 1
             print("enter sharded optimizer (SHARD_GRAD_OP-like)," if shard else "enter NO SHARD only,", flush=True)
             eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
-                                     sync_module_states=True, shard_optimizer=shard)
+                                     sync_module_states=True, shard_optimizer=shard, replica_group=tp_group)
             for blk in model.blocks:
                 blk.recompute = bool(tr.get("activation_checkpointing", False))
             optimizer = cl.load_optimizer(eng, "adamw", {"lr": float(mc["lr"]), "weight_decay": float(mc["weight_decay"]),

@@ -28,6 +28,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import tp as _tp
+
 BF, F32 = torch.bfloat16, torch.float32
 _ALIGN = 128  # elements; keeps every view 256-byte aligned
 
@@ -62,15 +64,23 @@ class Bucket:
         self.pending = 0
         self.handle = None
         self.event = None
+        self.rep_views: List[torch.Tensor] = []    # gradient ranges of the parameters replicated over a tensor-parallel group
 
 
 class HipDataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (),
                  is_lowp=None, sync_module_states: bool = True, overlap: bool = True,
-                 transposed_copies: bool = True, shard_optimizer: bool = False):
+                 transposed_copies: bool = True, shard_optimizer: bool = False, replica_group=None):
+        """replica_group: the tensor-parallel group of this rank (dist/tp.py).  The parameters that are NOT split
+        over it are replicas whose gradients agree only up to the summation order of the few atomic reductions
+        (conv weight gradients, variable-aggregation tables) -- and AdamW turns an ulp of difference in a near-zero
+        gradient into +-lr.  Their gradient ranges (laid out first inside every unit) are therefore overwritten
+        with the group's first rank's after the data-parallel reduction, which keeps the replicas bit-identical."""
         super().__init__()
         self.module = module
         self.pg = process_group
+        self.replica_group = replica_group if (replica_group is not None and dist.is_initialized()
+                                               and dist.get_world_size(replica_group) > 1) else None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.shard = bool(shard_optimizer)
@@ -92,6 +102,9 @@ class HipDataParallel(nn.Module):
         for uname, ps in units:
             lo = [(n, p) for n, p in ps if is_lowp(n, p)]
             hi = [(n, p) for n, p in ps if not is_lowp(n, p)]
+            if self.replica_group is not None:      # replicas first, tensor-parallel shards after (stable order)
+                lo.sort(key=lambda np_: hasattr(np_[1], "_o2_tp"))
+                hi.sort(key=lambda np_: hasattr(np_[1], "_o2_tp"))
             plan.append((uname, lo, hi))
             ulo = sum(_round_up(p.numel()) for _, p in lo)
             if self.shard:
@@ -118,8 +131,11 @@ class HipDataParallel(nn.Module):
         for uname, lo, hi in plan:
             bk = Bucket(uname)
             s32, s16 = o32, o16
+            rep16 = rep32 = 0                       # length of the replicated prefix of the bf16 / fp32 range
             for n, p in lo:
                 k = p.numel()
+                if not hasattr(p, "_o2_tp"):
+                    rep16 = o16 - s16 + _round_up(k)
                 self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
                 p.data = self.flat32[o32:o32 + k].view(p.shape)
                 p._o2c = self.flat16[o16:o16 + k].view(p.shape)
@@ -152,6 +168,8 @@ class HipDataParallel(nn.Module):
             s32h, sg = o32, og32
             for n, p in hi:
                 k = p.numel()
+                if not hasattr(p, "_o2_tp"):
+                    rep32 = og32 - sg + _round_up(k)
                 self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
                 p.data = self.flat32[o32:o32 + k].view(p.shape)
                 p.grad = self.g32[og32:og32 + k].view(p.shape)
@@ -169,6 +187,8 @@ class HipDataParallel(nn.Module):
                     self.opt_state_size += og32 - sg
                 else:
                     self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=s32h))
+            if self.replica_group is not None:
+                bk.rep_views = [v for v in (self.g16[s16:s16 + rep16], self.g32[sg:sg + rep32]) if v.numel()]
             self.buckets.append(bk)
         if not self.shard:
             self.opt_state_size = n32                      # moments laid out like flat32 (checkpoint format)
@@ -211,6 +231,7 @@ class HipDataParallel(nn.Module):
                 if hasattr(p, "_o2g"):
                     p._o2_fresh = True
         self._launched = []
+        self._replicas_synced = False
 
     def _hi_hook(self, p):
         self.grad_ready(p)
@@ -283,6 +304,11 @@ class HipDataParallel(nn.Module):
                 bk.handle = None           # idempotent: a second call (e.g. scaler.step after a captured step) is a no-op
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.replica_group is not None and not self._replicas_synced:
+            for bk in self.buckets:
+                for v in bk.rep_views:
+                    _tp.broadcast_first(v, self.replica_group)
+            self._replicas_synced = True
 
     # ---- nn.Module surface -----------------------------------------------------------------------------
     def forward(self, *a, **k):

@@ -77,6 +77,18 @@ def all_reduce_max(t: torch.Tensor, group) -> torch.Tensor:
     return t
 
 
+def broadcast_first(t: torch.Tensor, group) -> torch.Tensor:
+    """in-place broadcast from the group's first rank (host-staged under gloo, see all_reduce_sum)"""
+    src = dist.get_global_rank(group, 0)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+        return t
+    dist.broadcast(t, src=src, group=group)
+    return t
+
+
 class IdentityFwdAllReduceBwd(torch.autograd.Function):
     """input of a column-parallel Linear: identity forward, SUM of the partial input gradients backward
     (reference `F_Identity_B_AllReduce`, utils/dist_functions.py:430-445)"""
@@ -118,15 +130,9 @@ def sync_replicated(module: torch.nn.Module, group) -> None:
     `initial_0.pth` hand-off when training from scratch (examples/intermediate_downscaling.py:83-112)."""
     if group_size(group) == 1:
         return
-    src = dist.get_global_rank(group, 0)
     for name, p in module.named_parameters():
         if split_kind(name) is None and not name.endswith(_SUMMED_BIASES):
-            if p.is_cuda and dist.get_backend(group) == "gloo":
-                host = p.detach().cpu()
-                dist.broadcast(host, src=src, group=group)
-                p.copy_(host)
-            else:
-                dist.broadcast(p.data, src=src, group=group)
+            broadcast_first(p.data, group)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

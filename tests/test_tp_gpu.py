@@ -164,7 +164,7 @@ def _train_worker(rank, world, port, q):
         tp.sync_replicated(m, grp)
         cl.manual_seed(0, 0)                                         # seeded by data-parallel rank: same on both
         eng = cl.HipDataParallel(m, process_group=dp, unit_types=(Block, torch.nn.Sequential),
-                                 sync_module_states=True)
+                                 sync_module_states=True, replica_group=grp)
         m.blocks[0].recompute = True
         opt = cl.load_optimizer(eng, "adamw", {"lr": 1e-3, "weight_decay": 1e-5, "betas": (0.9, 0.99)})
         scaler = cl.HipGradScaler(init_scale=1024.0, sync_world=True)
@@ -174,7 +174,7 @@ def _train_worker(rank, world, port, q):
         eng.train()
         lossf = Bayesian_TV(aggregate_only=True)
         losses = []
-        for _ in range(3):
+        for _ in range(5):
             pred = eng(x, c["in_vars"], c["out_vars"])
             loss = lossf(clip_replace_constant(y, pred, c["out_vars"]), y, var_names=c["out_vars"], var_weights=VW)
             opt.zero_grad()
@@ -182,7 +182,7 @@ def _train_worker(rank, world, port, q):
             scaler.step(opt)
             assert not scaler.update()
             losses.append(float(loss))
-        assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
         sds = [None] * world
         dist.all_gather_object(sds, ({k: v.cpu() for k, v in eng.state_dict().items()}, losses), group=grp)
         (a, la), (b, lb) = sds
@@ -190,8 +190,9 @@ def _train_worker(rank, world, port, q):
         for k in a:
             same = torch.equal(a[k], b[k])
             if tp.split_kind(k) is None:
-                # replicated tensors: identical up to the order of the var-agg backward's atomic adds
-                assert same or _rel_l2(a[k], b[k]) < 1e-4, k
+                # replicas stay BIT-identical: the engine overwrites their gradients with the first rank's (the conv /
+                # var-agg backward's atomic adds differ in summation order, AdamW would amplify that to +-lr)
+                assert same, (k, _rel_l2(a[k], b[k]))
             else:
                 assert not same, k
         q.put((rank, "ok", losses))
