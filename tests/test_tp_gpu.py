@@ -205,3 +205,59 @@ def _train_worker(rank, world, port, q):
 
 def test_tp2_train_steps_keep_replicas_in_sync():
     print(_spawn(_train_worker))
+
+
+def _block_worker(rank, world, port, shape, q):
+    """one transformer Block at a headline shape: head-split pair vs the single-rank fused node (same weights)"""
+    try:
+        from climate_learn.dist import tp
+        from climate_learn.models.hub.components.vit_blocks import Block
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        grp = dist.new_group(list(range(world)))
+        D, H, L, B = shape
+        torch.manual_seed(3)
+        with torch.device("cuda"):
+            full = Block(D, H, qkv_bias=True, mlp_ratio=4.0)
+            mine = Block(D, H, qkv_bias=True, mlp_ratio=4.0, tensor_par_size=world, tensor_par_group=grp)
+        with torch.no_grad():
+            for n, p in full.named_parameters():
+                if n.endswith("bias"):
+                    p.normal_(0.0, 0.02)
+        sd = {k: v.cpu() for k, v in full.state_dict().items()}
+        mine.load_state_dict(tp.shard_state_dict(sd, world, rank, H))
+        full.eval(), mine.eval()
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(B, L, D, generator=g).to(torch.bfloat16).cuda()
+        dy = (torch.randn(B, L, D, generator=g) * 0.1).to(torch.bfloat16).cuda()
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya = mine(xa)
+        ya.backward(dy)
+        yb = full(xb)
+        yb.backward(dy)
+        torch.cuda.synchronize()
+        # sampled rows (the full tensors are 50 MB each): first / last / a stride through the middle
+        rows = torch.cat([torch.arange(0, 64), torch.arange(L // 2 - 32, L // 2 + 32), torch.arange(L - 64, L)]).cuda()
+        assert _rel_l2(ya[:, rows], yb[:, rows]) < 1e-2, _rel_l2(ya[:, rows], yb[:, rows])
+        assert _rel_l2(xa.grad[:, rows], xb.grad[:, rows]) < 2e-2, _rel_l2(xa.grad[:, rows], xb.grad[:, rows])
+        worst = []
+        gfull = dict(full.named_parameters())
+        for n, p in mine.named_parameters():
+            kind = tp.split_kind(n)
+            want = gfull[n].grad
+            want = tp._cut(want, kind, world, rank, H) if kind is not None else want
+            worst.append((_rel_l2(p.grad, want), n))
+        worst.sort(reverse=True)
+        assert worst[0][0] < 2e-2, worst[:4]
+        q.put((rank, "ok", worst[:2]))
+    except Exception:
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [(3072, 24, 8192, 1), (8192, 32, 2048, 1)], ids=["interm_1b", "interm_10b_L2048"])
+def test_tp2_block_at_headline_widths(shape):
+    """interm_1b: D 3072 / 24 heads of 128 / 8192 tokens; interm_10b width: D 8192 / 32 heads of 256"""
+    print(_spawn(_block_worker, shape))
