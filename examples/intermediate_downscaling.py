@@ -30,7 +30,7 @@ from climate_learn.data.processing.era5_constants import CONSTANTS  # noqa: E402
 from climate_learn.dist.profile import *  # noqa: E402,F401,F403
 from climate_learn.models.hub.components.pos_embed import interpolate_pos_embed  # noqa: E402
 from climate_learn.models.hub.components.vit_blocks import Block  # noqa: E402
-from climate_learn.trainer import training_step  # noqa: E402
+from climate_learn.trainer import training_step, validation_step  # noqa: E402
 from climate_learn.utils.fused_attn import FusedAttn  # noqa: E402
 
 
@@ -127,6 +127,7 @@ def main():
                                   "drop_rate": mc["drop_rate"], "tensor_par_size": tp, "tensor_par_group": tp_group,
                                   "FusedAttn_option": FusedAttn.CK if data_type == "bfloat16" else FusedAttn.DEFAULT})
             model, train_loss = out[0], out[1]
+            val_losses, val_transforms = out[2], out[5]
             ck = None
             suffix = "_rank_" + str(tp_rank) if tp > 1 else ""      # per tensor-parallel rank files (reference :52,:72)
             if tr.get("checkpoint") and os.path.exists(str(tr["checkpoint"]) + suffix):
@@ -196,6 +197,18 @@ def main():
                             "scheduler_state_dict": scheduler.state_dict()},
                            "checkpoints/climate/interm_epoch_" + str(epoch) + ".ckpt" + suffix)
             del model_states, optimizer_states
+            # validation pass: rmse / pearson / mean_bias on denormalised fields + mse, eval mode.  The reference has the
+            # block but switches it off (`if False:`, :801-822); `trainer.validate: true` switches it on here.
+            if tr.get("validate", False):
+                with torch.no_grad():
+                    eng.eval()
+                    if world_rank == 0:
+                        print("val epoch ", epoch, flush=True)
+                    for batch_idx, batch in enumerate(dm.val_dataloader()):
+                        losses = validation_step(batch, batch_idx, eng, device, val_losses, val_transforms)
+                        if world_rank == 0:
+                            print("val epoch: ", epoch, "batch_idx", batch_idx, "world_rank", world_rank, " losses ",
+                                  {k: round(float(v), 6) for k, v in losses.items()}, flush=True)
             if world_size > 1:
                 dist.barrier()
     if world_size > 1:

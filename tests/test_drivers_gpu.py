@@ -176,3 +176,22 @@ def test_inference_driver_reports_stitched_metrics(tmp_path):
         vals = [float(v) for v in m.group(1).split(",")]
         assert len(vals) == 4 and all(v == v for v in vals)          # 3 channels + aggregate, finite
     assert os.path.exists(os.path.join(tmp_path, "0_prediction.png"))
+
+
+def test_training_driver_validation_pass(tmp_path):
+    """`trainer.validate: true` runs the reference's (switched-off) validation block: rmse / pearson / mean_bias on
+    denormalised fields + mse, per output variable and aggregate, in eval mode after every epoch"""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=2, validate=True)
+    conf["model"].update(depth=1, warmup_epochs=1)
+    conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=2)
+    cfg = os.path.join(tmp_path, "v.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out = _run("intermediate_downscaling.py", cfg, tmp_path)
+    vals = re.findall(r"val epoch:  (\d+) batch_idx (\d+) world_rank 0  losses  (\{.*\})", out)
+    assert len(vals) >= 2 and {v[0] for v in vals} == {"0", "1"}
+    d = eval(vals[-1][2])
+    for metric in ("rmse", "pearson", "mean_bias", "mse"):
+        assert "val/%s:aggregate" % metric in d and "val/%s:total_precipitation_24hr" % metric in d, d.keys()
+        assert d["val/%s:aggregate" % metric] == d["val/%s:aggregate" % metric]        # not NaN
+    assert d["val/rmse:aggregate"] > 0 and -1.0 <= d["val/pearson:aggregate"] <= 1.0
