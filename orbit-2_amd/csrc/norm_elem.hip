@@ -80,21 +80,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+  // gamma is row-invariant: unpacked once per wave would cost 48 VGPRs; it stays packed (6 x 16 B per lane)
+  u32x4 gp[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    gp[c] = ch < nch ? *reinterpret_cast<const u32x4*>(gamma + ch * 8) : (u32x4){0u, 0u, 0u, 0u};
+  }
   for (int rr = 0; rr < LN_RPW; ++rr) {
     const int row = pw * LN_RPW + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
     const bf16_t* xr = x + (size_t)row * D;
     const bf16_t* dyr = dy + (size_t)row * D;
+    // every global load of the row is issued here, up front (x, dy and the residual-stream gradient), and the row
+    // stays PACKED in registers between the statistics pass and the dx pass: one HBM round trip per row instead
+    // of a second trip through L1/L2 plus a late dres fetch
+    u32x4 xp[NC], dp[NC], rp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nch) {
+        xp[c] = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+        dp[c] = *reinterpret_cast<const u32x4*>(dyr + ch * 8);
+        if (dres) rp[c] = *reinterpret_cast<const u32x4*>(dres + (size_t)row * D + ch * 8);
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nch) {
         float xv[8], dv[8], gv[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), xv);
-        unpack8(*reinterpret_cast<const u32x4*>(dyr + ch * 8), dv);
-        unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), gv);
+        unpack8(xp[c], xv);
+        unpack8(dp[c], dv);
+        unpack8(gp[c], gv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xhat = (xv[j] - mu) * rs;
@@ -112,14 +132,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       const int ch = lane + c * 64;
       if (ch < nch) {
         float xv[8], dv[8], gv[8], o[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), xv);
-        unpack8(*reinterpret_cast<const u32x4*>(dyr + ch * 8), dv);
-        unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), gv);
+        unpack8(xp[c], xv);
+        unpack8(dp[c], dv);
+        unpack8(gp[c], gv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rs * (dv[j] * gv[j] - s1 - (xv[j] - mu) * rs * s2);
         if (dres) {
           float rv[8];
-          unpack8(*reinterpret_cast<const u32x4*>(dres + (size_t)row * D + ch * 8), rv);
+          unpack8(rp[c], rv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += rv[j];
         }
