@@ -563,36 +563,52 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------
 // small fp32 GEMM (table algebra; sizes ~ [115 x D] x [D x D]): 64x64 tile, 16x16 threads, 4x4 micro-tile
 // ------------------------------------------------------------------------------------------
-template <int RM>   // block tile = (16*RM) x 64; RM = 4 (64 rows) or 1 (16 rows: skinny-M problems fill the chip)
+// BK: k-depth of one staged step.  The skinny form is a serial chain of (global load -> LDS -> barrier) steps whose
+// cost is the load latency, not the 16 FMAs: BK = 64 makes the chain 4x shorter with 4x the bytes in flight per step.
+template <int RM, int BK = 16>   // block tile = (16*RM) x 64; RM = 4 (64 rows) or 1 (16 rows: skinny-M problems fill the chip)
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                     int ldc, int ta, int tb, float alpha, float beta) {
   constexpr int TMB = 16 * RM;
-  __shared__ float sA[16][TMB + 1];
-  __shared__ float sB[16][64 + 1];
+  __shared__ float sA[BK][TMB + 1];
+  __shared__ float sB[BK][64 + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * TMB, n0 = blockIdx.x * 64;
   float acc[RM][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int e = threadIdx.x; e < 16 * TMB; e += 256) {
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // all global loads of the step are issued before the first LDS store (the store loop would otherwise
+    // serialise one memory round trip per element)
+    constexpr int NA = BK * TMB / 256, NB = BK * 64 / 256;
+    float ra[NA], rb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = threadIdx.x + i * 256;
       int kk, mm;
-      if (ta) { mm = e % TMB; kk = e / TMB; } else { kk = e & 15; mm = e >> 4; }
+      if (ta) { mm = e % TMB; kk = e / TMB; } else { kk = e % BK; mm = e / BK; }
       const int gm = m0 + mm, gk = k0 + kk;
-      float v = 0.f;
-      if (gm < M && gk < K) v = ta ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-      sA[kk][mm] = v;
+      ra[i] = (gm < M && gk < K) ? (ta ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
     }
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = threadIdx.x + i * 256;
       int kk, nn;
-      if (tb) { kk = e & 15; nn = e >> 4; } else { nn = e & 63; kk = e >> 6; }
+      if (tb) { kk = e % BK; nn = e / BK; } else { nn = e & 63; kk = e >> 6; }
       const int gn = n0 + nn, gk = k0 + kk;
-      float v = 0.f;
-      if (gn < N && gk < K) v = tb ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
-      sB[kk][nn] = v;
+      rb[i] = (gn < N && gk < K) ? (tb ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (ta) sA[e / TMB][e % TMB] = ra[i]; else sA[e % BK][e / BK] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (tb) sB[e % BK][e / BK] = rb[i]; else sB[e >> 6][e & 63] = rb[i];
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
+    for (int kk = 0; kk < BK; ++kk) {
       float a[RM], b[4];
 #pragma unroll
       for (int i = 0; i < RM; ++i) a[i] = sA[kk][ty * RM + i];
@@ -748,7 +764,7 @@ extern "C" int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M,
                        alpha, beta);
   } else {
     dim3 grid((N + 63) / 64, (M + 15) / 16), block(256);
-    hipLaunchKernelGGL(sgemm_kernel<1>, grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
+    hipLaunchKernelGGL((sgemm_kernel<1, 64>), grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
                        alpha, beta);
   }
   O2_CHECK_LAUNCH();
