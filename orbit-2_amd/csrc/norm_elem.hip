@@ -176,6 +176,108 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     *reinterpret_cast<f32x4*>(pout + e) = *reinterpret_cast<const f32x4*>(ln_red + e);
 }
 
+// Row-shared form.  Wide rows (D > 4096, interm_10b: D = 8192): the per-wave form above would keep 2 x 8 x 16 gradient
+// accumulators plus the packed row in registers and spill.  Here the TPB/64 waves of the block share every row, each
+// thread owning the chunks tid, tid + TPB, ..: a quarter of the accumulators per thread, one LDS exchange + barrier per row for the two
+// row statistics (double-buffered slots), the next row's loads issued before that barrier, and the block's partial
+// dgamma / dbeta row written straight from registers (the waves own disjoint columns).
+template <int NCW, int TPB = 256, int RPB = 4 * LN_RPW>
+__global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ gamma,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ part, int rows, int D) {
+  __shared__ float red[2][TPB / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = D >> 3;
+  const int row0 = blockIdx.x * RPB;
+  const int nrow = (rows - row0) < RPB ? (rows - row0) : RPB;
+  float dg[NCW][8], db[NCW][8];
+  u32x4 gp[NCW];
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) {
+    const int ch = tid + c * TPB;
+    gp[c] = ch < nch ? *reinterpret_cast<const u32x4*>(gamma + ch * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+  }
+  u32x4 xp[NCW], dp[NCW], rp[NCW], xn[NCW], dn[NCW], rn[NCW];
+  auto load_row = [&](int row, u32x4* xo, u32x4* dyo, u32x4* ro) {
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) {
+      const int ch = tid + c * TPB;
+      if (ch < nch) {
+        xo[c] = *reinterpret_cast<const u32x4*>(x + (size_t)row * D + ch * 8);
+        dyo[c] = *reinterpret_cast<const u32x4*>(dy + (size_t)row * D + ch * 8);
+        if (dres) ro[c] = *reinterpret_cast<const u32x4*>(dres + (size_t)row * D + ch * 8);
+      }
+    }
+  };
+  if (nrow > 0) load_row(row0, xp, dp, rp);
+  for (int rr = 0; rr < nrow; ++rr) {
+    const int row = row0 + rr;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) {
+      if (tid + c * TPB < nch) {
+        float xv[8], dv[8], gv[8];
+        unpack8(xp[c], xv); unpack8(dp[c], dv); unpack8(gp[c], gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xhat = (xv[j] - mu) * rs;
+          const float g = dv[j] * gv[j];
+          s1 += g; s2 += g * xhat;
+          dg[c][j] += dv[j] * xhat; db[c][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { red[rr & 1][wave][0] = s1; red[rr & 1][wave][1] = s2; }
+    if (rr + 1 < nrow) load_row(row + 1, xn, dn, rn);      // in flight across the barrier
+    __syncthreads();
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) { s1 += red[rr & 1][w][0]; s2 += red[rr & 1][w][1]; }
+    s1 /= (float)D; s2 /= (float)D;
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) {
+      const int ch = tid + c * TPB;
+      if (ch < nch) {
+        float xv[8], dv[8], gv[8], o[8];
+        unpack8(xp[c], xv); unpack8(dp[c], dv); unpack8(gp[c], gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (dv[j] * gv[j] - s1 - (xv[j] - mu) * rs * s2);
+        if (dres) {
+          float rv[8];
+          unpack8(rp[c], rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += rv[j];
+        }
+        u32x4 ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = pack_bf2(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<u32x4*>(dx + (size_t)row * D + ch * 8) = ov;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) { xp[c] = xn[c]; dp[c] = dn[c]; rp[c] = rn[c]; }
+  }
+  float* pout = part + (size_t)blockIdx.x * 2 * D;
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) {
+    const int ch = tid + c * TPB;
+    if (ch < nch) {
+      *reinterpret_cast<f32x4*>(pout + ch * 8) = (f32x4){dg[c][0], dg[c][1], dg[c][2], dg[c][3]};
+      *reinterpret_cast<f32x4*>(pout + ch * 8 + 4) = (f32x4){dg[c][4], dg[c][5], dg[c][6], dg[c][7]};
+      *reinterpret_cast<f32x4*>(pout + D + ch * 8) = (f32x4){db[c][0], db[c][1], db[c][2], db[c][3]};
+      *reinterpret_cast<f32x4*>(pout + D + ch * 8 + 4) = (f32x4){db[c][4], db[c][5], db[c][6], db[c][7]};
+    }
+  }
+}
+
 // out[which][col] = beta*out + sum_p part[p][which][col]; 32 columns x 8 partial-groups per block
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D,
                                                             void* dgamma, void* dbeta, int fp32, float beta) {
@@ -530,13 +632,22 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
   if (ws_floats < nparts * 2 * D) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nc = (D / 8 + 63) / 64;
+  const int npart_used = nparts / 4;
+  if (D == 3072) {   // interm_1b width: two waves share each row, 3 chunks per thread (363 vs 414 us at 65536 rows)
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<3, 128>), dim3(nparts / 4), dim3(128), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D);
+  } else if (nc > 8) {   // wide rows: the four waves share each row (D <= LN_MAXD = 8192 -> 4 chunks per thread)
+    hipLaunchKernelGGL(ln_bwd_wide_kernel<4>, dim3(nparts / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D);
+  } else {
 #define CALL(N)                                                                                                  \
   hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(nparts / 4), dim3(256), 2 * D * sizeof(float), s, (const bf16_t*)dy, (const bf16_t*)x, \
                      (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D)
   LN_DISPATCH(nc, CALL);
 #undef CALL
+  }
   O2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, nparts / 4, D, dgamma, dbeta,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, npart_used, D, dgamma, dbeta,
                      grads_fp32, beta_acc);
   O2_CHECK_LAUNCH();
   return O2_OK;

@@ -182,7 +182,7 @@ def test_sgemm(hip):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("D", [64, 256, 1024, 3072])
+@pytest.mark.parametrize("D", [64, 256, 1024, 3072, 5120, 8192])      # > 4096: the wide-row backward kernel
 def test_layernorm(hip, D):
     rows = 200
     g = torch.Generator().manual_seed(D)

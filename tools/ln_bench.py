@@ -7,7 +7,7 @@ def t(f,n=10):
     torch.cuda.synchronize(); e0.record()
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)/n
-M,D=65536,3072
+M,D=(int(sys.argv[1]),int(sys.argv[2])) if len(sys.argv)>2 else (65536,3072)
 x=torch.randn(M,D,device='cuda').bfloat16(); dy=torch.randn(M,D,device='cuda').bfloat16(); dres=torch.randn(M,D,device='cuda').bfloat16()
 g=torch.randn(D,device='cuda').bfloat16(); b=torch.randn(D,device='cuda').bfloat16()
 y,mean,rstd=_hip.layernorm_fwd(x,g,b)
