@@ -632,20 +632,40 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
   if (ws_floats < nparts * 2 * D) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nc = (D / 8 + 63) / 64;
-  const int npart_used = nparts / 4;
-  if (D == 3072) {   // interm_1b width: two waves share each row, 3 chunks per thread (363 vs 414 us at 65536 rows)
-    hipLaunchKernelGGL((ln_bwd_wide_kernel<3, 128>), dim3(nparts / 4), dim3(128), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D);
-  } else if (nc > 8) {   // wide rows: the four waves share each row (D <= LN_MAXD = 8192 -> 4 chunks per thread)
-    hipLaunchKernelGGL(ln_bwd_wide_kernel<4>, dim3(nparts / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D);
-  } else {
+  // row-shared form for the model widths (8m / 117m / 1b / 10b); 64 rows per block, 16 when there are few rows (the
+  // small grids: 4096 rows would otherwise occupy 64 CUs).  The workspace holds 4 partial rows per 64 input rows.
+  const bool few = rows < 32768;
+  const int npart_used = few ? (rows + 15) / 16 : nparts / 4;
+#define WIDE(NCW, TPB)                                                                                              \
+  do {                                                                                                              \
+    if (few)                                                                                                        \
+      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, 16>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,   \
+                         (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws,  \
+                         rows, D);                                                                                  \
+    else                                                                                                            \
+      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, 64>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,   \
+                         (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws,  \
+                         rows, D);                                                                                  \
+  } while (0)
+  if (D == 3072) WIDE(3, 128);          // 363 vs 414 us (per-wave form) at 65536 rows
+  else if (D == 1024) WIDE(1, 128);
+  else if (D == 256) WIDE(1, 64);
+  else if (nc > 8) WIDE(4, 256);        // D in (4096, 8192]: the per-wave form spills (1127 -> 115 us at D = 8192)
+  else if (few) {
+    // other widths with few rows: per-wave form, its partition (64 rows per block)
 #define CALL(N)                                                                                                  \
   hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(nparts / 4), dim3(256), 2 * D * sizeof(float), s, (const bf16_t*)dy, (const bf16_t*)x, \
                      (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, D)
-  LN_DISPATCH(nc, CALL);
+    LN_DISPATCH(nc, CALL);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, nparts / 4, D, dgamma, dbeta,
+                       grads_fp32, beta_acc);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
+  } else {
+    LN_DISPATCH(nc, CALL);
 #undef CALL
   }
+#undef WIDE
   O2_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, npart_used, D, dgamma, dbeta,
                      grads_fp32, beta_acc);

@@ -182,9 +182,10 @@ def test_sgemm(hip):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("D", [64, 256, 1024, 3072, 5120, 8192])      # > 4096: the wide-row backward kernel
-def test_layernorm(hip, D):
-    rows = 200
+@pytest.mark.parametrize("D,rows", [(64, 200), (256, 200), (1024, 200), (3072, 200), (5120, 200), (8192, 200),
+                                    (256, 33000), (1024, 33000), (3072, 33000), (2048, 33000)])
+def test_layernorm(hip, D, rows):
+    """the backward has a per-wave and a row-shared form, each with a few-rows (< 32768) and a many-rows partition"""
     g = torch.Generator().manual_seed(D)
     x = rt(torch.randn(rows, D, generator=g) * 2 + 0.5)
     gam, bet = rt(1 + 0.1 * torch.randn(D, generator=g)), rt(0.1 * torch.randn(D, generator=g))
