@@ -84,7 +84,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", rank=world_rank, world_size=world_size, device_id=device)
+        # RCCL, one rank per GPU.  ORBIT2_DIST_BACKEND=gloo exists for rehearsing the multi-rank control flow (groups,
+        # per-rank checkpoints, tensor-parallel collectives staged through the host) with several ranks on ONE card.
+        backend = os.environ.get("ORBIT2_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=world_rank, world_size=world_size, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=world_rank, world_size=world_size)
 
     tr, par, mc, dc = conf["trainer"], conf["parallelism"], conf["model"], conf["data"]
     max_epochs, batch_size = tr["max_epochs"], tr["batch_size"]

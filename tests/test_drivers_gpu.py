@@ -195,3 +195,50 @@ def test_training_driver_validation_pass(tmp_path):
         assert "val/%s:aggregate" % metric in d and "val/%s:total_precipitation_24hr" % metric in d, d.keys()
         assert d["val/%s:aggregate" % metric] == d["val/%s:aggregate" % metric]        # not NaN
     assert d["val/rmse:aggregate"] > 0 and -1.0 <= d["val/pearson:aggregate"] <= 1.0
+
+
+def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path):
+    """`parallelism.tensor_par: 2` end to end: two ranks of one tensor-parallel group (gloo rendezvous, both on the box's
+    single card), reference rank layout, per-rank checkpoint files `<ckpt>_rank_<r>` with the reference's split shapes,
+    identical losses on both ranks, resume from the per-rank files."""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=2)
+    conf["parallelism"].update(tensor_par=2, simple_ddp=1, fsdp=1)
+    conf["model"].update(depth=2, warmup_epochs=1)
+    conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=2)
+    cfg = os.path.join(tmp_path, "tp.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+
+    def run_pair():
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE="2", RANK=str(r),
+                       LOCAL_RANK="0", ORBIT2_DIST_BACKEND="gloo")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "intermediate_downscaling.py"), cfg],
+                                          cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0, o[-1500:] + e[-3000:]
+        return outs[0][0]
+
+    out = run_pair()
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 4 and all(l == l and 0 < l < 1e4 for l in losses)
+    D, tp = conf["model"]["embed_dim"], 2
+    cks = [torch.load(os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt_rank_%d" % r), map_location="cpu")
+           for r in range(2)]
+    for ck in cks:
+        sd = ck["model_state_dict"]
+        assert sd["blocks.0.attn.qkv.weight"].shape == (3 * D // tp, D)
+        assert sd["blocks.0.mlp.fc2.weight"].shape == (D, 4 * D // tp)
+        assert sd["var_agg.kv.weight"].shape == (2 * D // tp, D)
+        assert sd["head.0.weight"].shape == (D, D)
+    a, b = cks[0]["model_state_dict"], cks[1]["model_state_dict"]
+    assert torch.equal(a["head.0.weight"], b["head.0.weight"]) and torch.equal(a["norm.weight"], b["norm.weight"])
+    assert not torch.equal(a["blocks.0.attn.qkv.weight"], b["blocks.0.attn.qkv.weight"])
+    # resume both ranks from their own files for one more epoch
+    conf["trainer"].update(max_epochs=3, checkpoint=os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt"))
+    yaml.safe_dump(conf, open(cfg, "w"))
+    out2 = run_pair()
+    assert "model resume from checkpoint" in out2
+    assert re.findall(r"epoch:  (\d+) batch_idx 0 ", out2) == ["2"]
