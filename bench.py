@@ -130,7 +130,11 @@ def main():
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("ORBIT2_DIST_BACKEND", "nccl")     # gloo: multi-rank rehearsal on one card (tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import climate_learn as cl
     from climate_learn import _hip

@@ -242,3 +242,65 @@ def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path):
     out2 = run_pair()
     assert "model resume from checkpoint" in out2
     assert re.findall(r"epoch:  (\d+) batch_idx 0 ", out2) == ["2"]
+
+
+@pytest.mark.parametrize("mode", ["simple_ddp", "fsdp"])
+def test_training_driver_two_data_parallel_ranks_one_card(tmp_path, mode):
+    """the multi-rank data-parallel control flow on GPU tensors (bucket all-reduce / sharded optimizer on the side stream,
+    found_inf agreement, rank-0 checkpoint) with two ranks sharing the box's card over gloo; RCCL itself needs one GPU per
+    rank and is exercised by the round-end scaling run"""
+    conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
+    conf["trainer"].update(max_epochs=2, batch_size=2)
+    conf["parallelism"].update(**{"simple_ddp": 1, "fsdp": 1, mode: 2})
+    conf["model"].update(depth=2, warmup_epochs=1)
+    conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=3)
+    cfg = os.path.join(tmp_path, "dp.yaml")
+    yaml.safe_dump(conf, open(cfg, "w"))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29644", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0",
+                   ORBIT2_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "intermediate_downscaling.py"), cfg],
+                                      cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-1500:] + e[-3000:]
+    out = outs[0][0]
+    assert ("enter sharded optimizer" in out) == (mode == "fsdp")
+    losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
+    assert len(losses) == 6 and all(l == l and 0 < l < 1e4 for l in losses)
+    ck = torch.load(os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt"), map_location="cpu")
+    assert all(torch.isfinite(v).all() for v in ck["model_state_dict"].values())
+
+
+def test_bench_contract_two_ranks_one_card(tmp_path):
+    """bench.py's multi-rank path (barrier-bracketed timing, MAX over ranks, ONE JSON line from rank 0, whole-job value)
+    rehearsed with two ranks on the box's card over gloo; also with --tensor-par 2"""
+    import json
+
+    def run(extra):
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0",
+                       ORBIT2_DIST_BACKEND="gloo")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                                           "--warmup", "1", "--model", "interm_8m", "--grid", "32x64", "--batch", "2",
+                                           "--no-cpu-baseline"] + extra, cwd=tmp_path, env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0, o[-1500:] + e[-3000:]
+        keep = lambda o: [l for l in o.splitlines() if l.strip() and not l.startswith("[Gloo]")]   # gloo's own chatter
+        assert keep(outs[1][0]) == []                                # only rank 0 prints
+        lines = keep(outs[0][0])
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    d = run([])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job samples / max-rank time
+    assert d["roofline"]["launches"] > 0
+    t = run(["--tensor-par", "2"])
+    assert t["config"]["parallelism"] == "dp1xtp2" and t["config"]["global_batch"] == 2
+    assert abs(t["value"] - 2 * 1e3 / t["ms_per_step"]) < 1e-6 * t["value"]
