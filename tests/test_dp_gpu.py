@@ -1,0 +1,108 @@
+"""Data-parallel gradient semantics on GPU tensors: two ranks (sharing the box's card, gloo) each take half of a batch;
+the bucket-reduced gradient, scaled by the 1/N the fused AdamW folds in, must equal the single-rank gradient of the
+whole batch (the loss is a batch mean), and both ranks must hold the same parameters after the step."""
+import os
+import socket
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _worker(rank, world, port, shard, q):
+    try:
+        import sys
+        sys.path.insert(0, HERE)
+        from test_model_gpu import CASES, VW
+        import climate_learn as cl
+        from climate_learn.metrics import Bayesian_TV
+        from climate_learn.models.hub import Res_Slim_ViT
+        from climate_learn.models.hub.components.vit_blocks import Block
+        from climate_learn.trainer import training_step
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        solo = [dist.new_group([r]) for r in range(world)][0]          # rank 0's single-rank group (all ranks create it)
+        c = CASES["v7c3_hd64"]
+
+        def build():
+            torch.manual_seed(7)
+            m = Res_Slim_ViT(c["default_vars"], c["grid"], len(c["in_vars"]), len(c["out_vars"]), 1, patch_size=2,
+                             embed_dim=c["D"], depth=2, decoder_depth=1, num_heads=c["heads"], drop_path=0.0,
+                             drop_rate=0.0, learn_pos_emb=True).cuda()
+            m.data_config(156.0, c["grid"], len(c["in_vars"]), len(c["out_vars"]))
+            return m
+
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, len(c["in_vars"]), *c["grid"], generator=g)
+        y = torch.randn(4, len(c["out_vars"]), c["grid"][0] * 4, c["grid"][1] * 4, generator=g)
+        lossf = Bayesian_TV(aggregate_only=True)
+
+        def one_step(eng, xb, yb):
+            opt = cl.load_optimizer(eng, "adamw", {"lr": 1e-3, "weight_decay": 0.0, "betas": (0.9, 0.99)})
+            eng.train()
+            loss = training_step((xb.cuda(), yb.cuda(), c["in_vars"], c["out_vars"]), 0, eng, "cuda", VW, lossf)
+            opt.zero_grad()
+            loss.backward()
+            eng.finish_grad_sync()
+            grads = {n: (p._o2g if hasattr(p, "_o2g") else p.grad).detach().float().clone()
+                     for n, p in eng.module.named_parameters() if p.requires_grad}
+            opt.step()
+            return float(loss), grads
+
+        eng = cl.HipDataParallel(build(), unit_types=(Block, torch.nn.Sequential), shard_optimizer=shard)
+        l2, g2 = one_step(eng, x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2])
+        sd = {k: v.cpu() for k, v in eng.state_dict().items()}
+        both = [None] * world
+        dist.all_gather_object(both, (l2, sd))
+        for k in both[0][1]:
+            assert torch.equal(both[0][1][k], both[1][1][k]), k            # replicas identical after the step
+        if rank == 0:
+            ref = cl.HipDataParallel(build(), process_group=solo, unit_types=(Block, torch.nn.Sequential))
+            l1, g1 = one_step(ref, x, y)
+            assert abs(0.5 * (both[0][0] + both[1][0]) - l1) < 2e-3 * abs(l1), (both[0][0], both[1][0], l1)
+            if not shard:      # (sharded: a rank holds the reduced gradient of its own chunk only)
+                worst = sorted(((_rel_l2(g2[n] / world, g1[n]), n) for n in g1), reverse=True)
+                assert worst[0][0] < 3e-2, worst[:4]
+            # the updated parameters agree up to AdamW's sign amplification of near-zero gradients: bounded by 2 lr
+            ref_sd = ref.state_dict()
+            for k, v in sd.items():
+                assert float((v - ref_sd[k].cpu()).abs().max()) <= 2.01e-3, k
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", [False, True], ids=["all_reduce", "sharded_optimizer"])
+def test_two_ranks_equal_one_rank_with_the_whole_batch(shard):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shard, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert r[1] == "ok", "rank %d:\n%s" % (r[0], r[1])
