@@ -197,13 +197,15 @@ def test_training_driver_validation_pass(tmp_path):
     assert d["val/rmse:aggregate"] > 0 and -1.0 <= d["val/pearson:aggregate"] <= 1.0
 
 
-def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path):
-    """`parallelism.tensor_par: 2` end to end: two ranks of one tensor-parallel group (gloo rendezvous, both on the box's
-    single card), reference rank layout, per-rank checkpoint files `<ckpt>_rank_<r>` with the reference's split shapes,
-    identical losses on both ranks, resume from the per-rank files."""
+@pytest.mark.parametrize("ddp", [1, 2], ids=["tp2", "dp2xtp2"])
+def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path, ddp):
+    """`parallelism.tensor_par: 2` end to end: the ranks of one (or two data-parallel) tensor-parallel group(s) (gloo
+    rendezvous, all on the box's single card), reference rank layout, per-rank checkpoint files `<ckpt>_rank_<r>` with the
+    reference's split shapes, resume from the per-rank files."""
     conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
     conf["trainer"].update(max_epochs=2, batch_size=2)
-    conf["parallelism"].update(tensor_par=2, simple_ddp=1, fsdp=1)
+    conf["parallelism"].update(tensor_par=2, simple_ddp=ddp, fsdp=1)
+    world = 2 * ddp
     conf["model"].update(depth=2, warmup_epochs=1)
     conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=2)
     cfg = os.path.join(tmp_path, "tp.yaml")
@@ -211,8 +213,8 @@ def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path):
 
     def run_pair():
         procs = []
-        for r in range(2):
-            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE="2", RANK=str(r),
+        for r in range(world):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE=str(world), RANK=str(r),
                        LOCAL_RANK="0", ORBIT2_DIST_BACKEND="gloo")
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "intermediate_downscaling.py"), cfg],
                                           cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
