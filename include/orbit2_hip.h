@@ -63,6 +63,11 @@ int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream);
  * C[M,N] = alpha * op(A) * op(B) + beta*C, row-major fp32; ta/tb: 0 = as stored, 1 = transposed. */
 int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                      int ta, int tb, float alpha, float beta, void* stream);
+/* same product with a caller-owned fp32 workspace: skinny problems (a few rows against a D x D weight) are split over K
+ * into orbit2_sgemm_f32_ws_floats(M,N,K) / (M*N) slabs and combined deterministically; 0 floats = no split is planned */
+int64_t orbit2_sgemm_f32_ws_floats(int M, int N, int K);
+int orbit2_sgemm_f32_ws(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        int ta, int tb, float alpha, float beta, float* ws, int64_t ws_floats, void* stream);
 
 /* ---- LayerNorm (vit_blocks.py:46,63; res_slimvit.py:104,294): eps 1e-5, affine ------------ */
 int orbit2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,

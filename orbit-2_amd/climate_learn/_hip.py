@@ -176,8 +176,12 @@ def gemm_grouped(problems):
 def sgemm(A, B, out, M, N, K, lda, ldb, ldc, ta=False, tb=False, alpha=1.0, beta=0.0):
     for t, nm in ((A, "A"), (B, "B"), (out, "C")):
         _dev(t, F32, nm)
-    _chk(lib().orbit2_sgemm_f32(_p(A), _p(B), _p(out), M, N, K, lda, ldb, ldc, int(ta), int(tb), C.c_float(alpha),
-                                C.c_float(beta), _stream()), "orbit2_sgemm_f32")
+    L = lib()
+    L.orbit2_sgemm_f32_ws_floats.restype = C.c_int64
+    n = int(L.orbit2_sgemm_f32_ws_floats(M, N, K))
+    ws = torch.empty(n, dtype=F32, device=out.device) if n else None
+    _chk(L.orbit2_sgemm_f32_ws(_p(A), _p(B), _p(out), M, N, K, lda, ldb, ldc, int(ta), int(tb), C.c_float(alpha),
+                               C.c_float(beta), _p(ws), C.c_int64(n), _stream()), "orbit2_sgemm_f32_ws")
     return out
 
 

@@ -568,25 +568,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 template <int RM, int BK = 16>   // block tile = (16*RM) x 64; RM = 4 (64 rows) or 1 (16 rows: skinny-M problems fill the chip)
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int M, int N, int K, int lda, int ldb,
-                                                    int ldc, int ta, int tb, float alpha, float beta) {
+                                                    int ldc, int ta, int tb, float alpha, float beta, int kchunk,
+                                                    size_t zstride) {
+  // split-K: block z multiplies k in [z*kchunk, (z+1)*kchunk) into its own [M, N] slab at C + z*zstride (alpha = 1,
+  // beta = 0 there; sgemm_reduce_kernel sums the slabs).  One slab (kchunk = K) is the plain product.
+  const int kbase = blockIdx.z * kchunk;
+  const int Kend = (kbase + kchunk) < K ? (kbase + kchunk) : K;
+  C += (size_t)blockIdx.z * zstride;
   constexpr int TMB = 16 * RM;
   __shared__ float sA[BK][TMB + 1];
   __shared__ float sB[BK][64 + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * TMB, n0 = blockIdx.x * 64;
   float acc[RM][4] = {};
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // all global loads of the step are issued before the first LDS store (the store loop would otherwise
-    // serialise one memory round trip per element)
-    constexpr int NA = BK * TMB / 256, NB = BK * 64 / 256;
-    float ra[NA], rb[NB];
+  // register double-buffering: the global loads of step k+1 are in flight while step k is multiplied out of LDS (and
+  // all loads of a step are issued before the first LDS store: a fused load/store loop would serialise one memory
+  // round trip per element)
+  constexpr int NA = BK * TMB / 256, NB = BK * 64 / 256;
+  float ra[NA], rb[NB];
+  auto load_step = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = threadIdx.x + i * 256;
       int kk, mm;
       if (ta) { mm = e % TMB; kk = e / TMB; } else { kk = e % BK; mm = e / BK; }
       const int gm = m0 + mm, gk = k0 + kk;
-      ra[i] = (gm < M && gk < K) ? (ta ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
+      ra[i] = (gm < M && gk < Kend) ? (ta ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -594,8 +601,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
       int kk, nn;
       if (tb) { kk = e % BK; nn = e / BK; } else { nn = e & 63; kk = e >> 6; }
       const int gn = n0 + nn, gk = k0 + kk;
-      rb[i] = (gn < N && gk < K) ? (tb ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.f;
+      rb[i] = (gn < N && gk < Kend) ? (tb ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.f;
     }
+  };
+  load_step(kbase);
+  for (int k0 = kbase; k0 < Kend; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = threadIdx.x + i * 256;
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
       if (tb) sB[e % BK][e / BK] = rb[i]; else sB[e >> 6][e & 63] = rb[i];
     }
     __syncthreads();
+    if (k0 + BK < Kend) load_step(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; ++kk) {
       float a[RM], b[4];
@@ -632,6 +643,18 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
       float* c = C + (size_t)m * ldc + n;
       *c = alpha * acc[i][j] + (beta != 0.f ? beta * *c : 0.f);
     }
+  }
+}
+
+// C = alpha * sum_z ws[z] + beta * C   (deterministic combine of the split-K slabs)
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M,
+                                                           int N, int ldc, int S, float alpha, float beta) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += ws[(size_t)z * n + e];
+    float* c = C + (size_t)(e / N) * ldc + (e % N);
+    *c = alpha * s + (beta != 0.f ? beta * *c : 0.f);
   }
 }
 
@@ -754,19 +777,56 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   return O2_OK;
 }
 
-extern "C" int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
-                                int ldc, int ta, int tb, float alpha, float beta, void* stream) {
+// split-K plan of the skinny table products: enough slabs to put >= ~1024 workgroups on the chip, >= 4 staged k-steps each
+static int sgemm_splits(int M, int N, int K) {
+  const long blocks = (long)((N + 63) / 64) * (M > 32 ? (M + 63) / 64 : (M + 15) / 16);
+  if (blocks >= 512 || K < 1024) return 1;
+  int s = (int)((1024 + blocks - 1) / blocks);
+  const int maxs = K / 256;
+  s = s < maxs ? s : maxs;
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+extern "C" int64_t orbit2_sgemm_f32_ws_floats(int M, int N, int K) {
+  const int s = sgemm_splits(M, N, K);
+  return s > 1 ? (int64_t)s * M * N : 0;
+}
+
+extern "C" int orbit2_sgemm_f32_ws(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                   int ldc, int ta, int tb, float alpha, float beta, float* ws, int64_t ws_floats,
+                                   void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return O2_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
   const long blocks64 = (long)((N + 63) / 64) * ((M + 63) / 64);
+  int S = sgemm_splits(M, N, K);
+  if (S > 1 && (!ws || ws_floats < (int64_t)S * M * N)) S = 1;      // no workspace: plain product
+  int kchunk = K;
+  if (S > 1) kchunk = (((K + S - 1) / S) + 63) / 64 * 64;
+  float* out = S > 1 ? ws : C;
+  const int ldo = S > 1 ? N : ldc;
+  const float al = S > 1 ? 1.f : alpha, be = S > 1 ? 0.f : beta;
+  const size_t zs = (size_t)M * N;
   if (blocks64 >= 512) {
-    dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-    hipLaunchKernelGGL(sgemm_kernel<4>, grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
-                       alpha, beta);
+    dim3 grid((N + 63) / 64, (M + 63) / 64, 1), block(256);
+    hipLaunchKernelGGL((sgemm_kernel<4, 16>), grid, block, 0, st, A, B, C, M, N, K, lda, ldb, ldc, ta, tb, alpha, beta, K,
+                       (size_t)0);
+  } else if (M > 32) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, S), block(256);
+    hipLaunchKernelGGL((sgemm_kernel<4, 32>), grid, block, 0, st, A, B, out, M, N, K, lda, ldb, ldo, ta, tb, al, be, kchunk, zs);
   } else {
-    dim3 grid((N + 63) / 64, (M + 15) / 16), block(256);
-    hipLaunchKernelGGL((sgemm_kernel<1, 64>), grid, block, 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ta, tb,
-                       alpha, beta);
+    dim3 grid((N + 63) / 64, (M + 15) / 16, S), block(256);
+    hipLaunchKernelGGL((sgemm_kernel<1, 64>), grid, block, 0, st, A, B, out, M, N, K, lda, ldb, ldo, ta, tb, al, be, kchunk, zs);
   }
   O2_CHECK_LAUNCH();
+  if (S > 1 && blocks64 < 512) {
+    hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256 < 4096 ? ((int64_t)M * N + 255) / 256 : 4096)), dim3(256), 0, st, ws, C, M, N, ldc, S, alpha,
+                       beta);
+    O2_CHECK_LAUNCH();
+  }
   return O2_OK;
+}
+
+extern "C" int orbit2_sgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                int ta, int tb, float alpha, float beta, void* stream) {
+  return orbit2_sgemm_f32_ws(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, alpha, beta, nullptr, 0, stream);
 }

@@ -179,6 +179,20 @@ def test_sgemm(hip):
         out = torch.empty(M, N, device="cuda")
         hip.sgemm(A.cuda(), B.cuda(), out, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb)
         assert nerr(out, ref) < 1e-5
+    # skinny products against a wide weight are split over K (workspace slabs + deterministic combine)
+    for (M, N, K, ta, tb) in [(24, 3072, 3072, 0, 0), (115, 1536, 3000, 0, 1), (1, 512, 4096, 0, 1), (24, 640, 2048, 1, 0),
+                              (115, 96, 8192, 1, 1)]:
+        assert hip.lib().orbit2_sgemm_f32_ws_floats(M, N, K) > 0
+        A = torch.randn((K, M) if ta else (M, K), generator=g)
+        B = torch.randn((N, K) if tb else (K, N), generator=g)
+        C0 = torch.randn(M, N, generator=g)
+        ref = 0.5 * ((A.t() if ta else A).double() @ (B.t() if tb else B).double()).float() + 2.0 * C0
+        out = C0.clone().cuda()
+        hip.sgemm(A.cuda(), B.cuda(), out, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, alpha=0.5, beta=2.0)
+        assert nerr(out, ref) < 1e-5
+        again = C0.clone().cuda()
+        hip.sgemm(A.cuda(), B.cuda(), again, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, alpha=0.5, beta=2.0)
+        assert torch.equal(out, again)                     # no atomics: bit-reproducible
 
 
 # ---------------------------------------------------------------------------------------------
