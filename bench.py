@@ -263,6 +263,7 @@ def main():
         f_dense = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"])
         f_exec = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"], folded_varagg=True)
         gm = prof.get("gemm_bf16", {"work": 0.0, "ms": 1.0, "launches": 0})
+        gl = prof.get("gemm_lib", {"work": 0.0, "ms": 0.0, "launches": 0})     # plain GEMMs handed to hipBLASLt
         traffic = None     # HBM bytes per GEMM launch from the committed PMC passes of the same configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
@@ -288,7 +289,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "algorithmic_bytes_per_launch": gm.get("bytes", None),
-                         "kernel": "orbit2_gemm_bf16 = gemm256_kernel (NT ring) + gemm128_kernel (K-strided forms), all launches of the timed region", "launches": gm["launches"],
+                         "kernel": "orbit2_gemm_bf16 = gemm256_kernel (NT ring) + gemm128_kernel, hand-written: every GEMM "
+                                   "with a fused epilogue, all its launches of the timed region"
+                                   + ("; the epilogue-free GEMMs (input / weight gradients) run in hipBLASLt, see "
+                                      "step_model.library_gemm" if gl["launches"] else
+                                      " (and the epilogue-free ones: ORBIT2_PLAIN_GEMM=own)"),
+                         "launches": gm["launches"],
                          "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
             "step_model": {
                 "model_flops_per_sample_dense": 3 * f_dense, "executed_flops_per_sample_folded_varagg": 3 * f_exec,
@@ -297,6 +303,10 @@ def main():
                 "attn_fwd_tflops": (prof["attn_fwd"]["work"] / prof["attn_fwd"]["ms"] / 1e9) if "attn_fwd" in prof else None,
                 "attn_bwd_tflops": (prof["attn_bwd"]["work"] / prof["attn_bwd"]["ms"] / 1e9) if "attn_bwd" in prof else None,
                 "gemm_ms_per_step": gm["ms"] / a.steps,
+                "library_gemm": {"provider": "hipBLASLt via torch.matmul (plain GEMMs only: dX = dY.W, dW = dY^T.X)",
+                                 "launches": gl["launches"], "ms_per_step": gl["ms"] / a.steps,
+                                 "tflops": (gl["work"] / gl["ms"] / 1e9) if gl["launches"] else None,
+                                 "share_of_gemm_flops": gl["work"] / max(1.0, gl["work"] + gm["work"])},
                 "attn_ms_per_step": (prof.get("attn_fwd", {"ms": 0})["ms"] + prof.get("attn_bwd", {"ms": 0})["ms"]) / a.steps,
                 "final_loss": loss_val, "loss_scale": scaler.get_scale()},
         }

@@ -478,3 +478,31 @@ def test_bad_arguments_are_refused_not_run(hip):
     with pytest.raises(HipBackendError):                       # more problems than one grouped launch takes
         hip.gemm_grouped([])
     torch.cuda.synchronize()                                   # nothing faulted
+
+
+def test_plain_gemm_library_and_own_kernel_agree(hip, monkeypatch):
+    """the epilogue-free GEMMs of the training step go to the library GEMM by default (ORBIT2_PLAIN_GEMM=own keeps
+    them on orbit2_gemm_bf16): both must give the same product, in every operand form the step uses, with and
+    without accumulation; small or strided problems stay on our kernel either way"""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 512, 384, 768
+    for a_kc, b_kc, beta in [(True, True, 0.0), (True, False, 0.0), (False, False, 0.0), (False, False, 1.0)]:
+        A = bf(torch.randn((M, K) if a_kc else (K, M), generator=g)).cuda()
+        B = bf(torch.randn((N, K) if b_kc else (K, N), generator=g)).cuda()
+        C0 = bf(torch.randn(M, N, generator=g)).cuda()
+        ref = (A.float() if a_kc else A.float().t()) @ (B.float().t() if b_kc else B.float()) + beta * C0.float()
+        outs = {}
+        for mode in (True, False):
+            monkeypatch.setattr(hip, "PLAIN_GEMM_LIBRARY", mode)
+            o = C0.clone()
+            hip.plain_gemm(A, B, o, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, beta=beta)
+            outs[mode] = o
+            assert nerr(o, ref) < 1e-2, (a_kc, b_kc, beta, mode)
+        assert nerr(outs[True], outs[False]) < 1e-2
+    # not dense (row stride > K) or small: our kernel, whatever the switch says
+    monkeypatch.setattr(hip, "PLAIN_GEMM_LIBRARY", True)
+    Abig = bf(torch.randn(M, K + 64, generator=g)).cuda()
+    W = bf(torch.randn(N, K, generator=g)).cuda()
+    o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.plain_gemm(Abig, W, o, M, N, K, K + 64, K, N)
+    assert nerr(o, Abig[:, :K].float() @ W.float().t()) < 1e-2
