@@ -1,8 +1,9 @@
 """climate_learn -- MI355X-native (gfx950) build of ORBIT-2's intermediate_downscaling hot path.
 
 Mirrors the reference package surface the driver uses (`import climate_learn as cl`): the load_* factories,
-`cl.data.IterDataModule`, the model / metrics registries, `FusedAttn`.  All compute goes through
-liborbit2_hip.so (include/orbit2_hip.h); there is no CPU fallback."""
+`cl.data.IterDataModule`, the model / metrics registries, `FusedAttn`.  The compute goes through
+liborbit2_hip.so (include/orbit2_hip.h) -- every fused op; only the epilogue-free backward GEMMs are handed to the
+library GEMM (hipBLASLt; ORBIT2_PLAIN_GEMM=own keeps them on our kernels too).  There is no CPU fallback."""
 from .utils.fused_attn import FusedAttn
 from .utils import loaders as _loaders
 
