@@ -169,6 +169,11 @@ def cpu_baseline(model_name, V, C):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the result: libraries that write banners to file descriptor 1 (RCCL prints its
+    # version block there at communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -368,7 +373,8 @@ def main():
             torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model, V, C)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
