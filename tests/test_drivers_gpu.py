@@ -307,3 +307,25 @@ def test_bench_contract_two_ranks_one_card(tmp_path):
     t = run(["--tensor-par", "2"])
     assert t["config"]["parallelism"] == "dp1xtp2" and t["config"]["global_batch"] == 2
     assert abs(t["value"] - 2 * 1e3 / t["ms_per_step"]) < 1e-6 * t["value"]
+
+
+def test_bench_single_rank_line_with_baselines(tmp_path):
+    """one rank, small model: ONE stdout line carrying `roofline`, `cpu_baseline` (oracle on the host) and, with
+    --eager-baseline, `gpu_eager_baseline` (the oracle as eager PyTorch on the GPU)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--model", "interm_8m",
+                        "--batch", "2", "--eager-baseline", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "bf16" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["unit"] == "TFLOP/s"
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    ge = d["gpu_eager_baseline"]
+    assert ge["value"] > 0 and ge["per_gpu_batch"] == 2
