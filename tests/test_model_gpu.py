@@ -491,3 +491,59 @@ def test_checkpoint_roundtrip_resumes_identically(tmp_path):
     b = [step(eng2, opt2, batch) for _ in range(2)]
     assert a[2:] == b, (a, b)          # bit-identical continuation (deterministic kernels, same lr, same moments)
     assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+
+
+def test_loss_scaler_dynamics_growth_overflow_skip_and_floor():
+    """HipGradScaler (the ShardedGradScaler the reference intends, driver :493-497,732-742): the scale doubles after
+    `growth_interval` clean steps; a non-finite gradient makes the fused AdamW skip the update ON DEVICE (parameters,
+    moments and step count untouched), halves the scale, and the scale never goes below `min_scale`; a graphed step
+    re-captures when the scale moved."""
+    import climate_learn as cl
+    from climate_learn.graphs import GraphedTrainStep
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub import Res_Slim_ViT
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    c = CASES["v5c1_hd64"]
+    torch.manual_seed(1)
+    m = Res_Slim_ViT(c["in_vars"], c["grid"], len(c["in_vars"]), len(c["out_vars"]), 1, patch_size=2, embed_dim=c["D"],
+                     depth=1, decoder_depth=1, num_heads=c["heads"], drop_path=0.0, drop_rate=0.0).cuda()
+    m.data_config(156.0, c["grid"], len(c["in_vars"]), len(c["out_vars"]))
+    eng = cl.HipDataParallel(m, unit_types=(Block, nn.Sequential))
+    opt = cl.load_optimizer(eng, "adamw", {"lr": 1e-3, "betas": (0.9, 0.99), "weight_decay": 0.0})
+    scaler = cl.HipGradScaler(init_scale=256.0, growth_interval=3, min_scale=128.0)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, len(c["in_vars"]), *c["grid"], generator=g).cuda()
+    y = torch.randn(2, len(c["out_vars"]), c["grid"][0] * 4, c["grid"][1] * 4, generator=g).abs().cuda()
+    batch, lossf, vw = (x, y, c["in_vars"], c["out_vars"]), Bayesian_TV(aggregate_only=True), {"total_precipitation_24hr": 1.0}
+    eng.train()
+
+    def step(poison=False):
+        loss = training_step(batch, 0, eng, torch.device("cuda"), vw, lossf)
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        if poison:
+            eng.finish_grad_sync()
+            eng.g16[7] = float("inf")                    # one overflowed bf16 gradient element
+        scaler.step(opt)
+        return scaler.update()
+
+    scales = []
+    for _ in range(3):
+        assert step() is False
+        scales.append(scaler.get_scale())
+    assert scales == [256.0, 256.0, 512.0]               # doubled after the 3rd clean step
+    before = eng.flat32.clone()
+    assert step(poison=True) is True                     # overflow: reported ...
+    assert torch.equal(eng.flat32, before)               # ... the update was skipped on device ...
+    assert scaler.get_scale() == 256.0                   # ... and the scale halved
+    assert step(poison=True) is True and scaler.get_scale() == 128.0
+    assert step(poison=True) is True and scaler.get_scale() == 128.0      # floor (driver :739-742)
+    assert step() is False and not torch.equal(eng.flat32, before)        # training resumes
+    # graphed step: same scaler, the capture follows a moved scale
+    gs = GraphedTrainStep(eng, lossf, batch, vw, scaler=scaler)
+    for _ in range(4):
+        gs()
+        scaler.step(opt)
+        scaler.update()
+    assert scaler.get_scale() == 256.0 and gs.captures == 2               # grew once (3 clean steps) -> one re-capture
