@@ -162,6 +162,7 @@ PLAIN_GEMM_LIBRARY = os.environ.get("ORBIT2_PLAIN_GEMM", "lib") != "own"
 def plain_gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, beta=0.0):
     """out[M,N] = op(A) op(B) (+ out if beta == 1), bf16, no epilogue.  Library GEMM (hipBLASLt through torch.matmul,
     the framework's binding of it) when enabled and the operands are dense; orbit2_gemm_bf16 otherwise."""
+    global PLAIN_GEMM_LIBRARY
     dense = (lda == (K if a_kc else M) and ldb == (K if b_kc else N) and ldc == N and out.dtype == BF
              and out.is_contiguous() and A.is_contiguous() and B.is_contiguous() and beta in (0.0, 1.0)
              and min(M, N, K) >= 256)
@@ -175,10 +176,18 @@ def plain_gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, beta=0.0
     if timer is not None:
         e0, e1 = timer.span("gemm_lib", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
         e0.record()
-    if beta == 0.0:
-        torch.matmul(Am, Bm, out=o)
-    else:
-        o.addmm_(Am, Bm)
+    try:
+        if beta == 0.0:
+            torch.matmul(Am, Bm, out=o)
+        else:
+            o.addmm_(Am, Bm)
+    except RuntimeError as exc:            # no usable library GEMM in this environment: our kernel does every GEMM
+        PLAIN_GEMM_LIBRARY = False
+        import warnings
+        warnings.warn("library GEMM failed (%s); plain GEMMs stay on orbit2_gemm_bf16 from now on" % str(exc)[:200])
+        if timer is not None:
+            timer.records["gemm_lib"].pop()
+        return gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=a_kc, b_kc=b_kc, beta=beta)
     if timer is not None:
         e1.record()
     return out

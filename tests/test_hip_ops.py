@@ -506,3 +506,11 @@ def test_plain_gemm_library_and_own_kernel_agree(hip, monkeypatch):
     o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     hip.plain_gemm(Abig, W, o, M, N, K, K + 64, K, N)
     assert nerr(o, Abig[:, :K].float() @ W.float().t()) < 1e-2
+    # a failing library GEMM (e.g. no hipBLASLt for the device) degrades to our kernel, once, with a warning
+    def boom(*a, **k):
+        raise RuntimeError("no library GEMM here")
+    monkeypatch.setattr(torch, "matmul", boom)
+    A = bf(torch.randn(M, K, generator=g)).cuda()
+    with pytest.warns(UserWarning, match="library GEMM failed"):
+        hip.plain_gemm(A, W, o, M, N, K, K, K, N)
+    assert nerr(o, A.float() @ W.float().t()) < 1e-2 and hip.PLAIN_GEMM_LIBRARY is False
