@@ -35,6 +35,14 @@ from climate_learn.utils.fused_attn import FusedAttn  # noqa: E402
 
 
 def seed_everything(seed, rank=0):
+    """Python's and numpy's global streams get the SAME seed on every rank (the reference calls random.seed(0)
+    everywhere); the data plane does not depend on them any more (private streams, data/iterdataset.py), torch's host
+    stream is only used for weight init.  Only the kernel seed stream (dropout / DropPath masks) is keyed by the
+    data-parallel rank."""
+    import random
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
     torch.manual_seed(seed)
     cl.manual_seed(seed, rank)
 

@@ -1,5 +1,6 @@
-"""smoke_step(): one tiny training step of the HIP path on cuda:0, checked against the CPU oracle.
-(Test-side helper: the only place besides tests/ and bench.py's cpu_baseline that touches oracle/.)"""
+"""TEST INFRASTRUCTURE (lives beside the oracle, outside the product package): builds a HIP model and the CPU oracle with
+identical weights, and smoke_step() = one tiny training step of the HIP path on cuda:0 checked against the oracle.
+Imported only by tests/ and __graft_entry__.smoke()."""
 import os
 import sys
 
@@ -9,11 +10,12 @@ import torch
 
 def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_vars=("total_precipitation_24hr",)):
     """(HIP model on cuda, oracle state dict + config on CPU) holding identical weights + a seeded batch."""
-    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    if root not in sys.path:
-        sys.path.insert(0, root)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "orbit-2_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
     from oracle import orbit2_oracle as O
-    from .models.hub import Res_Slim_ViT
+    from climate_learn.models.hub import Res_Slim_ViT
     consts = ["land_sea_mask", "orography", "lattitude", "landcover"]
     in_vars = consts + [v for v in out_vars]
     cfg = O.Config(in_vars, grid, len(out_vars), D, depth, dd, heads, spatial_resolution=156.0)
@@ -41,9 +43,9 @@ def nerr(a, b):
 
 
 def smoke_step():
-    from . import _hip
-    from .metrics import Bayesian_TV
-    from .trainer import training_step
+    from climate_learn import _hip
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.trainer import training_step
     assert torch.cuda.is_available(), "smoke() needs cuda:0"
     assert _hip.selftest() == 0, "MFMA / LDS layout self-test failed"
     model, sd, cfg, O, x, y, in_vars, out_vars = build_pair()

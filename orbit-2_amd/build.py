@@ -37,6 +37,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     digest, stamp = _source_digest(srcs, hdrs), LIB + ".srchash"
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB                  # the shipped library was built from exactly these sources
+    # The digest says the library does NOT come from these sources (or there is no record): file times cannot be trusted
+    # to find what is stale (they do not survive a snapshot copy), so everything is recompiled and relinked -- the stamp
+    # below is then only ever written for a library that was just built from the hashed sources.
+    force = True
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)

@@ -2,8 +2,8 @@
 
 Mirrors the reference package surface the driver uses (`import climate_learn as cl`): the load_* factories,
 `cl.data.IterDataModule`, the model / metrics registries, `FusedAttn`.  The compute goes through
-liborbit2_hip.so (include/orbit2_hip.h) -- every fused op; only the epilogue-free backward GEMMs are handed to the
-library GEMM (hipBLASLt; ORBIT2_PLAIN_GEMM=own keeps them on our kernels too).  There is no CPU fallback."""
+liborbit2_hip.so (include/orbit2_hip.h) -- every fused op and every GEMM of the step, forward and backward; no
+vendor-library GEMM is called.  There is no CPU fallback."""
 from .utils.fused_attn import FusedAttn
 from .utils import loaders as _loaders
 

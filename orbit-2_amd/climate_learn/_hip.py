@@ -149,50 +149,6 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, **kw):
     return out
 
 
-# ------------------------------------------------------------------------------------------------
-# Plain (epilogue-free) GEMMs of the training step: input gradients dX = dY.W and weight gradients dW = dY^T.X.  The brief
-# keeps hand-written kernels for the FUSED ops and allows the vendor library for plain library GEMMs; hipBLASLt's
-# kernels are 20-30 % faster than orbit2_gemm_bf16 on these shapes (tools/blaslt_compare.py: 1400-1570 vs 1150-1215
-# TFLOP/s NT, 1000-1165 vs 900-950 TN), worth 4.5 % of the interm_1b step.  ORBIT2_PLAIN_GEMM=own keeps them on
-# liborbit2_hip.so (what the kernel-level tests and the `own` rows of DESIGN 6b use); `gemm` itself never delegates.
-# ------------------------------------------------------------------------------------------------
-PLAIN_GEMM_LIBRARY = os.environ.get("ORBIT2_PLAIN_GEMM", "lib") != "own"
-
-
-def plain_gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, beta=0.0):
-    """out[M,N] = op(A) op(B) (+ out if beta == 1), bf16, no epilogue.  Library GEMM (hipBLASLt through torch.matmul,
-    the framework's binding of it) when enabled and the operands are dense; orbit2_gemm_bf16 otherwise."""
-    global PLAIN_GEMM_LIBRARY
-    dense = (lda == (K if a_kc else M) and ldb == (K if b_kc else N) and ldc == N and out.dtype == BF
-             and out.is_contiguous() and A.is_contiguous() and B.is_contiguous() and beta in (0.0, 1.0)
-             and min(M, N, K) >= 512)      # below that our 128^2 kernel wins (interm_8m: 4012 vs 3724 samples/s graphed)
-    if not (PLAIN_GEMM_LIBRARY and dense):
-        return gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=a_kc, b_kc=b_kc, beta=beta)
-    for t, nm in ((A, "A"), (B, "B"), (out, "C")):
-        _dev(t, BF, nm)
-    Am = A.reshape(-1)[:M * K].view(M, K) if a_kc else A.reshape(-1)[:M * K].view(K, M).t()
-    Bm = B.reshape(-1)[:N * K].view(N, K).t() if b_kc else B.reshape(-1)[:N * K].view(K, N)
-    o = out.reshape(-1)[:M * N].view(M, N)
-    if timer is not None:
-        e0, e1 = timer.span("gemm_lib", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
-        e0.record()
-    try:
-        if beta == 0.0:
-            torch.matmul(Am, Bm, out=o)
-        else:
-            o.addmm_(Am, Bm)
-    except RuntimeError as exc:            # no usable library GEMM in this environment: our kernel does every GEMM
-        PLAIN_GEMM_LIBRARY = False
-        import warnings
-        warnings.warn("library GEMM failed (%s); plain GEMMs stay on orbit2_gemm_bf16 from now on" % str(exc)[:200])
-        if timer is not None:
-            timer.records["gemm_lib"].pop()
-        return gemm(A, B, out, M, N, K, lda, ldb, ldc, a_kc=a_kc, b_kc=b_kc, beta=beta)
-    if timer is not None:
-        e1.record()
-    return out
-
-
 GEMM_MAX_GROUP = 8
 
 

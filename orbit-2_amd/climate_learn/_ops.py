@@ -1,8 +1,8 @@
 """Autograd functions that orchestrate the HIP kernels (climate_learn._hip) for the Res_Slim_ViT hot path.
 
 Each Function is one fused stage of the training step with a hand-written backward made of the same C-ABI
-kernels; the only ATen compute calls inside them are the epilogue-free backward GEMMs handed to the library GEMM
-(`_hip.plain_gemm`, switch ORBIT2_PLAIN_GEMM=own).  Precision policy = the reference's FSDP MixedPrecision
+kernels: every GEMM of the step, forward and backward, runs in liborbit2_hip.so (`orbit2_gemm_bf16` /
+`orbit2_gemm_bf16_grouped`); no vendor-library GEMM is called anywhere in the package.  Precision policy = the reference's FSDP MixedPrecision
 (examples/intermediate_downscaling.py:601-607): fp32 master parameters, bf16 compute copies and activations,
 fp32 accumulation inside the kernels, bf16 weight gradients.
 
@@ -115,10 +115,6 @@ def _dx(dy2d, W, M, N, K, **kw):
     the K-contiguous form (faster kernel); otherwise W is read through the hardware-transposing LDS path."""
     out = torch.empty(M, K, dtype=BF, device=dy2d.device)
     wt = getattr(W, "_o2ct", None)
-    if not kw:                      # no fused epilogue: a plain GEMM (library kernel unless ORBIT2_PLAIN_GEMM=own)
-        if wt is not None:
-            return _hip.plain_gemm(dy2d, wt, out, M, K, N, N, N, K, a_kc=True, b_kc=True)
-        return _hip.plain_gemm(dy2d, cw(W), out, M, K, N, N, K, K, a_kc=True, b_kc=False)
     if wt is not None:
         return _hip.gemm(dy2d, wt, out, M, K, N, N, N, K, a_kc=True, b_kc=True, **kw)
     return _hip.gemm(dy2d, cw(W), out, M, K, N, N, K, K, a_kc=True, b_kc=False, **kw)
@@ -127,7 +123,7 @@ def _dx(dy2d, W, M, N, K, **kw):
 def _dw(dy2d, x2d, W, b, M, N, K):
     """dW[N,K] = dy^T . x ; db[N] = colsum(dy).  Returns what backward must return for (W, b)."""
     sw = _GradSink(W)
-    _hip.plain_gemm(dy2d, x2d, sw.buf, N, K, M, N, K, K, a_kc=False, b_kc=False, beta=sw.beta)
+    _hip.gemm(dy2d, x2d, sw.buf, N, K, M, N, K, K, a_kc=False, b_kc=False, beta=sw.beta)
     gw = sw.done()
     gb = None
     if b is not None:
@@ -160,12 +156,8 @@ class _DwBatch:
 
     def flush(self):
         """launches the group; returns the per-problem values backward must return for the weights"""
-        if _hip.PLAIN_GEMM_LIBRARY:     # plain GEMMs: one library call each (falls back to our kernel when not dense)
-            for (dy2d, x2d, buf, N, K, M, lda, ldb, ldc, kw) in self.problems:
-                _hip.plain_gemm(dy2d, x2d, buf, N, K, M, lda, ldb, ldc, **kw)
-        else:                           # our kernel: the whole node as ONE grouped launch
-            for i in range(0, len(self.problems), _hip.GEMM_MAX_GROUP):
-                _hip.gemm_grouped(self.problems[i:i + _hip.GEMM_MAX_GROUP])
+        for i in range(0, len(self.problems), _hip.GEMM_MAX_GROUP):     # the whole node as ONE grouped launch
+            _hip.gemm_grouped(self.problems[i:i + _hip.GEMM_MAX_GROUP])
         out = [s.done() for s in self.sinks]
         self.problems, self.sinks, self.keep = [], [], []
         return out

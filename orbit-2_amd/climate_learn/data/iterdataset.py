@@ -83,8 +83,12 @@ def shard_range(n_files: int, rank: int, data_par_size: int, num_workers: int = 
 
 class NpyReader(IterableDataset):
     def __init__(self, inp_file_list, out_file_list, variables, out_variables, data_par_size: int = 1,
-                 data_par_group=None, shuffle=False, div=1, overlap=4, rank: Optional[int] = None):
+                 data_par_group=None, shuffle=False, div=1, overlap=4, rank: Optional[int] = None, seed: int = 0):
         super().__init__()
+        # The file order must be IDENTICAL on every rank (the [start:end] slices of shard_range are disjoint only then):
+        # the reference gets that from random.seed(0) on every rank; here the reader owns a private stream keyed by
+        # (seed, epoch) and never touches Python's global `random`.
+        self.seed, self.epoch = int(seed), 0
         assert len(inp_file_list) == len(out_file_list)
         self.inp_file_list = [f for f in inp_file_list if "climatology" not in f]
         self.out_file_list = [f for f in out_file_list if "climatology" not in f]
@@ -94,26 +98,31 @@ class NpyReader(IterableDataset):
         self.data_par_size, self.data_par_group = data_par_size, data_par_group
         self._rank = rank
 
+    def dp_rank(self) -> int:
+        """rank inside the DATA-parallel group: the ranks of one tensor-parallel group share it, so they read the same
+        files and (ShuffleIterableDataset) draw the same shuffle-buffer stream"""
+        if self._rank is not None:
+            return self._rank
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank(group=self.data_par_group)
+        return 0
+
     def _my_files(self):
         inp, out = list(self.inp_file_list), list(self.out_file_list)
         if self.shuffle:
             order = list(range(len(inp)))
-            random.shuffle(order)
+            random.Random(self.seed * 1000003 + self.epoch).shuffle(order)      # same permutation on every rank
             inp, out = [inp[i] for i in order], [out[i] for i in order]
         wi = torch.utils.data.get_worker_info()
         nw, wid = (wi.num_workers, wi.id) if wi is not None else (1, 0)
-        if self._rank is not None:
-            rank = self._rank
-        elif torch.distributed.is_available() and torch.distributed.is_initialized():
-            rank = torch.distributed.get_rank(group=self.data_par_group)
-        else:
-            rank = 0
+        rank = self.dp_rank()
         mult, rem, a, b = shard_range(len(inp), rank, self.data_par_size, nw, wid)
         inp, out = inp * mult + inp[:rem], out * mult + out[:rem]
         return inp[a:b], out[a:b]
 
     def __iter__(self):
         inp_files, out_files = self._my_files()
+        self.epoch += 1                      # the next pass over the data draws a new (still rank-independent) file order
         for pin, pout in zip(inp_files, out_files):
             din = np.load(pin)
             dout = din if pout == pin else np.load(pout)
@@ -181,21 +190,35 @@ class IndividualDataIter(IterableDataset):
 
 
 class ShuffleIterableDataset(IterableDataset):
-    def __init__(self, dataset, buffer_size):
+    """shuffle buffer with a private random stream keyed by (seed, epoch, data-parallel rank, worker): data-parallel ranks
+    draw different streams, the ranks of one tensor-parallel group (same data-parallel rank) identical ones -- their
+    partial products are summed as if the inputs were the same batch, so they must be"""
+
+    def __init__(self, dataset, buffer_size, seed: int = 0, dp_rank=None):
         super().__init__()
         assert buffer_size > 0
         self.dataset, self.buffer_size = dataset, buffer_size
+        self.seed, self.epoch, self._dp_rank = int(seed), 0, dp_rank
+
+    def _rank(self) -> int:
+        if callable(self._dp_rank):
+            return int(self._dp_rank())
+        return int(self._dp_rank or 0)
 
     def __iter__(self):
+        wi = torch.utils.data.get_worker_info()
+        wid = wi.id if wi is not None else 0
+        rng = random.Random(((self.seed * 1000003 + self.epoch) * 8191 + self._rank()) * 131 + wid)
+        self.epoch += 1
         buf = []
         for x in self.dataset:
             if len(buf) == self.buffer_size:
-                i = random.randint(0, self.buffer_size - 1)
+                i = rng.randint(0, self.buffer_size - 1)
                 yield buf[i]
                 buf[i] = x
             else:
                 buf.append(x)
-        random.shuffle(buf)
+        rng.shuffle(buf)
         while buf:
             yield buf.pop()
 

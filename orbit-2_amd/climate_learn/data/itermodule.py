@@ -151,10 +151,16 @@ class IterDataModule(SyntheticGridDataModule):
         from . import iterdataset as ID
         rd = ID.NpyReader(self._files(self.inp_root_dir, split), self._files(self.out_root_dir, split), self.in_vars,
                           self.out_vars, data_par_size=self.data_par_size, data_par_group=self.data_par_group,
-                          shuffle=shuffle, div=self.div, overlap=self.overlap)
+                          shuffle=shuffle, div=self.div, overlap=self.overlap, seed=self.seed)
+        # one loader per epoch (the driver asks for a fresh one every epoch): its number is the epoch of the shuffle streams,
+        # also when worker processes (which get copies of the datasets) do the iterating
+        calls = self.__dict__.setdefault("_loader_calls", {})
+        rd.epoch = calls.get(split, 0)
+        calls[split] = rd.epoch + 1
         ds = ID.IndividualDataIter(ID.Downscale(rd), self.transforms, self.output_transforms, subsample=self.subsample)
         if shuffle and self.buffer_size > 0:
-            ds = ID.ShuffleIterableDataset(ds, self.buffer_size)
+            ds = ID.ShuffleIterableDataset(ds, self.buffer_size, seed=self.seed, dp_rank=rd.dp_rank)
+            ds.epoch = rd.epoch
         return DataLoader(ds, batch_size=self.batch_size, drop_last=False, num_workers=self.num_workers,
                           collate_fn=ID.collate_fn)
 

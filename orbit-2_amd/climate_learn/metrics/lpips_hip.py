@@ -23,7 +23,7 @@ _TV_CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
 
 
 def random_lpips_state(seed: int = 0) -> Dict[str, torch.Tensor]:
-    """He-normal convolutions, small positive lins -- same recipe as the test oracle's stand-in weights."""
+    """He-normal convolutions, small positive lins -- same recipe as the stand-in weights the parity tests use."""
     g = torch.Generator(device="cpu").manual_seed(seed)      # CPU draws even inside a `with torch.device("cuda")` block
     sd, cin, i = {}, 3, 0
     for c in VGG16_CFG:

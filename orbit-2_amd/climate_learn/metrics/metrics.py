@@ -64,21 +64,31 @@ class PERCEPTUAL(Metric):
     """L1 + 0.5 * mean LPIPS-VGG16 (reference: metrics.py:119-187, functional.py:17-33).  Same constructor as the
     reference (device, model, aggregate_only, metainfo).  The reference's __call__ takes (pred, target) only, while
     training_step always passes var_names= / var_weights=: they are accepted and ignored here.
-    LPIPS weights: a state dict file named by $ORBIT2_LPIPS_WEIGHTS (lpips / torchvision key names), otherwise
-    seeded random weights (synthetic-throughput configuration; lpips' pretrained file is not in the reference tree)."""
+    LPIPS weights: a state dict file named by $ORBIT2_LPIPS_WEIGHTS (lpips / torchvision key names).  The reference
+    loads lpips' PRETRAINED VGG16 (`lpips.LPIPS(net='vgg')`); training against anything else is a different loss, so a
+    missing file is an error.  Seeded random stand-in weights (synthetic throughput runs, parity tests against the
+    restated graph) must be asked for explicitly: `synthetic_weights=True` or ORBIT2_LPIPS_SYNTHETIC=1.
+    Export the real ones on a machine that has the packages:
+        import lpips, torch; torch.save(lpips.LPIPS(net='vgg').state_dict(), 'lpips_vgg.pt')"""
 
-    def __init__(self, device, model, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None):
+    def __init__(self, device, model, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None,
+                 synthetic_weights: Optional[bool] = None):
         import os
-        import warnings
         from .lpips_hip import LPIPSVGG16
         super().__init__(aggregate_only, metainfo)
         self.model = model
         path = os.environ.get("ORBIT2_LPIPS_WEIGHTS")
+        if synthetic_weights is None:
+            synthetic_weights = os.environ.get("ORBIT2_LPIPS_SYNTHETIC", "0") == "1"
         state = None
         if path:
-            state = torch.load(path, map_location="cpu")
-        else:
-            warnings.warn("perceptual loss: no $ORBIT2_LPIPS_WEIGHTS file, using seeded random LPIPS-VGG16 weights")
+            state = torch.load(path, map_location="cpu", weights_only=True)
+        elif not synthetic_weights:
+            raise RuntimeError(
+                "perceptual loss: no LPIPS-VGG16 weights.  Set $ORBIT2_LPIPS_WEIGHTS to a state-dict file exported from "
+                "lpips.LPIPS(net='vgg') (or torchvision vgg16 + lpips lins); seeded random stand-in weights are only "
+                "used when asked for explicitly (synthetic_weights=True / ORBIT2_LPIPS_SYNTHETIC=1): a run that "
+                "optimises 0.5*LPIPS against a random network is not the reference's loss.")
         self.loss_fn = LPIPSVGG16(device, state)
 
     def __call__(self, pred, target, var_names: Optional[List[str]] = None,

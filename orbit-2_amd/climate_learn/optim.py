@@ -79,16 +79,44 @@ class HipAdamW(torch.optim.Optimizer):
         else:
             super().zero_grad(set_to_none)
 
+    # ---- checkpoint format: torch.optim.AdamW's ------------------------------------------------------------------
+    # state[i] = {step, exp_avg, exp_avg_sq} per parameter, i = position in param_groups (= model.parameters() order, the
+    # reference's).  It does not depend on the engine's flat layout, so a checkpoint written by the replicated engine, by
+    # the sharded one at any world size (whose unit ranges are padded to world * 128 elements), or by the reference's
+    # torch.optim.AdamW (`optimizer_state_dict` of its .ckpt files) loads into any of them.
+    def _params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def _offset32(self, p) -> int:
+        e = self.engine
+        off = p.data.storage_offset() - e.flat32.storage_offset()
+        if p.data.untyped_storage().data_ptr() != e.flat32.untyped_storage().data_ptr() or off < 0 \
+                or off + p.numel() > e.flat32.numel():
+            raise RuntimeError("parameter is not a view of the engine's flat master buffer")
+        return off
+
     def state_dict(self):
-        sd = super().state_dict()
-        sd["orbit2"] = {"step": self._step}
-        if self.engine is not None:
-            sd["orbit2"]["m"] = self._full_state(self.m)
-            sd["orbit2"]["v"] = self._full_state(self.v)
-        return sd
+        if self.engine is None:
+            sd = super().state_dict()
+            for st in sd["state"].values():                     # torch key names for the un-managed path too
+                if "m" in st:
+                    st["exp_avg"], st["exp_avg_sq"] = st.pop("m"), st.pop("v")
+                    st["step"] = torch.tensor(float(self._step))
+            sd["orbit2"] = {"step": self._step, "format": 2}
+            return sd
+        fm, fv = self._full_state(self.m), self._full_state(self.v)
+        state, idx = {}, []
+        for i, p in enumerate(self._params()):
+            off, n = self._offset32(p), p.numel()
+            state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": fm[off:off + n].view(p.shape),
+                        "exp_avg_sq": fv[off:off + n].view(p.shape)}
+            idx.append(i)
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        groups[0]["params"] = idx
+        return {"state": state, "param_groups": groups, "orbit2": {"step": self._step, "format": 2}}
 
     def _full_state(self, st):
-        """moments in the flat32 layout (the checkpoint format of the unsharded engine)"""
+        """moments in the flat32 layout of THIS engine (sharded: gathered from the ranks' chunks)"""
         e = self.engine
         if not e.shard:
             return st
@@ -100,6 +128,9 @@ class HipAdamW(torch.optim.Optimizer):
 
     def _load_full_state(self, st, full):
         e = self.engine
+        if full.numel() != e.flat32.numel():
+            raise RuntimeError("optimizer moments of %d elements do not fit this engine's layout (%d)"
+                               % (full.numel(), e.flat32.numel()))
         if not e.shard:
             st.copy_(full)
             return
@@ -107,13 +138,49 @@ class HipAdamW(torch.optim.Optimizer):
             st[sg["os"]:sg["os"] + sg["n"]].copy_(full[sg["o32"]:sg["o32"] + sg["n"]])
 
     def load_state_dict(self, sd):
+        sd = dict(sd)                                    # the caller's dict is left as it was
         extra = sd.pop("orbit2", None)
-        super().load_state_dict(sd)
-        if extra:
+        if self.engine is None:
+            sd["state"] = {k: ({"m": v["exp_avg"], "v": v["exp_avg_sq"]} if "exp_avg" in v else dict(v))
+                           for k, v in sd.get("state", {}).items()}
+            super().load_state_dict(sd)
+            steps = [float(v["step"]) for v in sd.get("state", {}).values() if "step" in v]
+            self._step = extra["step"] if extra else (int(max(steps)) if steps else 0)
+            return
+        for g, sg in zip(self.param_groups, sd.get("param_groups", [])):       # hyper-parameters (lr schedule position)
+            g.update({k: v for k, v in sg.items() if k != "params"})
+        if extra and "m" in extra:
+            # round-1 format: flat moments in the WRITING engine's layout -- only valid for an identical layout
+            if extra["m"].numel() != self.engine.flat32.numel() or self.engine.shard:
+                raise RuntimeError("this checkpoint holds flat optimizer moments in its writer's layout (round-1 format); "
+                                   "load it with the same engine mode and world size, then re-save")
+            self._load_full_state(self.m, extra["m"].to(self.m.device))
+            self._load_full_state(self.v, extra["v"].to(self.v.device))
             self._step = extra["step"]
-            if self.engine is not None and "m" in extra:
-                self._load_full_state(self.m, extra["m"].to(self.m.device))
-                self._load_full_state(self.v, extra["v"].to(self.v.device))
+            return
+        state = sd.get("state", {})
+        params = self._params()
+        if not state:
+            import warnings
+            warnings.warn("optimizer checkpoint holds no per-parameter state: AdamW moments and step count start from zero")
+            self._step = extra["step"] if extra else 0
+            return
+        fm, fv = torch.zeros_like(self.engine.flat32), torch.zeros_like(self.engine.flat32)
+        steps = []
+        for i, p in enumerate(params):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise RuntimeError("optimizer state %d has shape %s, parameter has %s"
+                                   % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            off, n = self._offset32(p), p.numel()
+            fm[off:off + n].copy_(st["exp_avg"].reshape(-1).to(fm.device, F32))
+            fv[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(fv.device, F32))
+            steps.append(float(st["step"]))
+        self._load_full_state(self.m, fm)
+        self._load_full_state(self.v, fv)
+        self._step = int(extra["step"]) if extra else (int(max(steps)) if steps else 0)
 
 
 class HipGradScaler:
@@ -128,6 +195,7 @@ class HipGradScaler:
         self.pg = process_group
         self.sync_world = sync_world     # found_inf is agreed over ALL ranks (tensor-parallel shards differ per rank)
         self._found = None
+        self._opt = None                 # the optimizer of the last step() (update() rolls its step count back on overflow)
 
     def get_scale(self):
         return self._scale
@@ -153,10 +221,15 @@ class HipGradScaler:
         optimizer.check_inf = False
         optimizer.grad_scale = 1.0
         self._found = fi
+        self._opt = optimizer
 
     def update(self):
         bad = bool(self._found.item() != 0.0) if self._found is not None else False
         if bad:
+            # the kernel skipped the update on device: like torch's GradScaler (which does not call optimizer.step() on an
+            # overflow) the step count behind the bias corrections must not advance either
+            if self._opt is not None:
+                self._opt._step -= 1
             self._scale = max(self._scale * self.backoff_factor, self.min_scale)
             self._good = 0
         else:
@@ -164,4 +237,5 @@ class HipGradScaler:
             if self._good >= self.growth_interval:
                 self._scale *= self.growth_factor
                 self._good = 0
+        self._opt = None
         return bad

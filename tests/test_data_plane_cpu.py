@@ -108,3 +108,71 @@ def test_iterdatamodule_on_disk(tmp_path):
     x, y, a, b = batches[0]
     assert x.shape[1:] == (5, h, w) and y.shape[1:] == (1, H, W) and a == iv and b == ov
     assert float(y.min()) >= 0.0                                    # log1p precipitation
+
+
+def _shard_worker(rank, world, root, port, q):
+    """dp2 x tp2 layout of the reference driver (tensor-parallel ranks adjacent): every rank reads its on-disk shard"""
+    import torch.distributed as dist
+    import climate_learn as cl
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tp = 2
+    dp_group = None
+    for i in range(tp):
+        g = dist.new_group([i + j * tp for j in range(world // tp)])
+        dp_group = g if rank % tp == i else dp_group
+    iv = ["land_sea_mask", "orography", "lattitude", "landcover", "total_precipitation_24hr"]
+    dm = cl.data.IterDataModule("downscaling", os.path.join(root, "lo"), os.path.join(root, "hi"), iv,
+                                ["total_precipitation_24hr"], data_par_size=world // tp, data_par_group=dp_group,
+                                batch_size=2, buffer_size=3, subsample=1, seed=5)
+    dm.setup()
+    epochs = []
+    for _ in range(2):
+        ids = []
+        for x, y, _, _ in dm.train_dataloader():
+            ids += [float(v) for v in x[:, 1, 0, 0]]          # the orography field carries the sample id
+        epochs.append(ids)
+    q.put((rank, epochs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_dp_ranks_read_disjoint_shards_and_tp_peers_identical_batches(tmp_path):
+    """the file order must be the same permutation on every rank (disjoint, complete data-parallel
+    shards) and the shuffle-buffer stream must depend on the DATA-parallel rank only (the ranks of a tensor-parallel group
+    sum partial products of what must be the same batch)."""
+    import socket
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(0)
+    iv = ["land_sea_mask", "orography", "lattitude", "landcover", "total_precipitation_24hr"]
+    nfiles, T = 6, 2
+    for root, (H, W), vs in ((tmp_path / "lo", (8, 16), iv), (tmp_path / "hi", (32, 64), ["total_precipitation_24hr"])):
+        os.makedirs(root / "train")
+        for sh in range(nfiles):
+            d = {v: np.abs(rng.normal(size=(T, 1, H, W))) * 1e-3 for v in vs}
+            if "orography" in d:
+                for t in range(T):
+                    d["orography"][t] = sh * 100 + t               # sample id, survives Normalize(0, 1)
+            np.savez(root / "train" / ("2000_%d.npz" % sh), **d)
+        np.save(root / "lat.npy", np.linspace(-80, 80, H))
+        np.save(root / "lon.npy", np.linspace(0, 350, W))
+        np.savez(root / "normalize_mean.npz", **{v: np.array([0.0]) for v in vs})
+        np.savez(root / "normalize_std.npz", **{v: np.array([1.0]) for v in vs})
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 4, str(tmp_path), port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(4))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    every = sorted(sh * 100 + t for sh in range(nfiles) for t in range(T))
+    for ep in range(2):
+        assert got[0][ep] == got[1][ep] and got[2][ep] == got[3][ep]       # tensor-parallel peers: the same batches
+        a, b = got[0][ep], got[2][ep]                                       # the two data-parallel ranks
+        assert not set(a) & set(b) and sorted(a + b) == every               # disjoint and complete
+    assert got[0][0] != got[0][1]                                           # a new epoch reshuffles

@@ -190,3 +190,119 @@ def test_engine_single_process_layout():
     for p in model.parameters():
         off = p.data.data_ptr() - base
         assert 0 <= off < eng.flat32.numel() * 4 and off % 256 == 0
+
+
+def _worker_optim_ckpt(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import climate_learn as cl
+        from climate_learn.models.hub.components.vit_blocks import Block
+        hp = {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5}
+
+        def make(shard):
+            torch.manual_seed(7)
+            model = _build()
+            eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential), overlap=False, shard_optimizer=shard)
+            return model, eng, cl.load_optimizer(eng, "adamw", dict(hp))
+
+        def expected(p, i, which):          # a value pattern that identifies (parameter, element, moment)
+            return (torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) % 97) + 100.0 * i + (0.5 if which else 0.0)
+
+        ms, es, os_ = make(True)
+        mr, er, or_ = make(False)
+        assert es.flat32.numel() != er.flat32.numel()          # the sharded layout is padded: offsets differ
+        # put known moments into the SHARDED optimizer (each rank holds its chunks only)
+        fm, fv = torch.zeros_like(es.flat32), torch.zeros_like(es.flat32)
+        for i, p in enumerate(ms.parameters()):
+            off = os_._offset32(p)
+            fm[off:off + p.numel()] = expected(p, i, 0).reshape(-1)
+            fv[off:off + p.numel()] = expected(p, i, 1).reshape(-1)
+        os_._load_full_state(os_.m, fm)
+        os_._load_full_state(os_.v, fv)
+        os_._step = 11
+        sd = os_.state_dict()                                  # collective: gathers the ranks' chunks
+        assert sd["orbit2"]["step"] == 11 and len(sd["state"]) == len(list(ms.parameters()))
+        for i, p in enumerate(ms.parameters()):
+            assert torch.equal(sd["state"][i]["exp_avg"], expected(p, i, 0)), i
+            assert torch.equal(sd["state"][i]["exp_avg_sq"], expected(p, i, 1)), i
+            assert float(sd["state"][i]["step"]) == 11.0
+        # sharded (world 2) -> replicated
+        or_.load_state_dict(sd)
+        assert or_._step == 11 and "orbit2" in sd
+        for i, p in enumerate(mr.parameters()):
+            off = or_._offset32(p)
+            assert torch.equal(or_.m[off:off + p.numel()].view(p.shape), expected(p, i, 0))
+            assert torch.equal(or_.v[off:off + p.numel()].view(p.shape), expected(p, i, 1))
+        # ... and back into a fresh sharded optimizer
+        ms2, es2, os2 = make(True)
+        os2.load_state_dict(or_.state_dict())
+        sd2 = os2.state_dict()
+        assert all(torch.equal(sd2["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"]) for i in sd["state"])
+        assert os2._step == 11
+        # a torch.optim.AdamW checkpoint (= the reference's optimizer_state_dict) loads too: moments and step count
+        torch.manual_seed(7)
+        mt = _build()
+        topt = torch.optim.AdamW(mt.parameters(), **hp)
+        g = torch.Generator().manual_seed(3)
+        for p in mt.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+        topt.step()
+        topt.step()
+        tsd = topt.state_dict()
+        os2.load_state_dict(tsd)
+        assert os2._step == 2
+        got = os2.state_dict()
+        for i in tsd["state"]:
+            assert torch.equal(got["state"][i]["exp_avg"], tsd["state"][i]["exp_avg"])
+        # an empty state is said out loud, a wrong-shaped one refused
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            or_.load_state_dict({"state": {}, "param_groups": tsd["param_groups"]})
+        assert any("start from zero" in str(x.message) for x in w)
+        bad = {"state": {0: {"step": torch.tensor(1.0), "exp_avg": torch.zeros(3), "exp_avg_sq": torch.zeros(3)}},
+               "param_groups": tsd["param_groups"]}
+        try:
+            or_.load_state_dict(bad)
+            raise AssertionError("shape mismatch accepted")
+        except RuntimeError:
+            pass
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_optimizer_checkpoint_is_layout_independent_world2_gloo():
+    """moments are saved per parameter (torch.optim.AdamW's format), so sharded(world = 2) ->
+    replicated -> sharded round-trips exactly although the sharded layout pads every unit, and a reference
+    torch.optim.AdamW state dict loads with its step count"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_optim_ckpt, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_skipped_step_does_not_advance_bias_correction():
+    """an overflow-skipped step leaves the AdamW step count where it was (torch's GradScaler does not
+    call optimizer.step() then)"""
+    import climate_learn as cl
+
+    class _Opt:
+        _step = 5
+    sc = cl.HipGradScaler(init_scale=1024.0)
+    sc._found, sc._opt = torch.tensor([1.0]), _Opt
+    assert sc.update() is True and _Opt._step == 4 and sc.get_scale() == 512.0
+    sc._found, sc._opt = torch.tensor([0.0]), _Opt
+    assert sc.update() is False and _Opt._step == 4

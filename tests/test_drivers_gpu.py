@@ -146,8 +146,11 @@ def test_training_driver_with_spatial_tiling(tmp_path):
     assert ck["model_state_dict"]["pos_embed"].shape[1] == 9 * 18
 
 
-def test_training_driver_daymet_like_perceptual_loss(tmp_path):
-    """configs/interm_1b_daymet.yaml (7 inputs, 3 outputs, hybrid perceptual loss) with a reduced model and grid"""
+def test_training_driver_daymet_like_perceptual_loss(tmp_path, monkeypatch):
+    """configs/interm_1b_daymet.yaml (7 inputs, 3 outputs, hybrid perceptual loss) with a reduced model and grid; the
+    seeded stand-in LPIPS weights are an explicit opt-in (without it, and without a weights file, the loss refuses)"""
+    monkeypatch.setenv("ORBIT2_LPIPS_SYNTHETIC", "1")
+    monkeypatch.delenv("ORBIT2_LPIPS_WEIGHTS", raising=False)
     conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_1b_daymet.yaml")))
     assert conf["trainer"]["train_loss"] == "perceptual" and len(conf["data"]["dict_in_variables"]["DAYMET_1"]) == 7
     conf["trainer"].update(max_epochs=2, batch_size=2)

@@ -480,37 +480,23 @@ def test_bad_arguments_are_refused_not_run(hip):
     torch.cuda.synchronize()                                   # nothing faulted
 
 
-def test_plain_gemm_library_and_own_kernel_agree(hip, monkeypatch):
-    """the epilogue-free GEMMs of the training step go to the library GEMM by default (ORBIT2_PLAIN_GEMM=own keeps
-    them on orbit2_gemm_bf16): both must give the same product, in every operand form the step uses, with and
-    without accumulation; small or strided problems stay on our kernel either way"""
+def test_backward_gemm_forms_own_kernel(hip, monkeypatch):
+    """the epilogue-free GEMMs of the training step (dX = dY.W in the NT / NN forms, dW = dY^T.X in the TN form, with and
+    without accumulation into the gradient bucket) run on orbit2_gemm_bf16 like every other GEMM: correct in every
+    form the step uses, and no vendor-library matmul is reachable (torch.matmul / addmm are booby-trapped here)"""
+    def boom(*a, **k):
+        raise AssertionError("vendor GEMM called from the product path")
+    for name in ("matmul", "mm", "addmm", "bmm"):
+        monkeypatch.setattr(torch, name, boom)
     g = torch.Generator().manual_seed(21)
     M, N, K = 512, 640, 768
     for a_kc, b_kc, beta in [(True, True, 0.0), (True, False, 0.0), (False, False, 0.0), (False, False, 1.0)]:
         A = bf(torch.randn((M, K) if a_kc else (K, M), generator=g)).cuda()
         B = bf(torch.randn((N, K) if b_kc else (K, N), generator=g)).cuda()
         C0 = bf(torch.randn(M, N, generator=g)).cuda()
-        ref = (A.float() if a_kc else A.float().t()) @ (B.float().t() if b_kc else B.float()) + beta * C0.float()
-        outs = {}
-        for mode in (True, False):
-            monkeypatch.setattr(hip, "PLAIN_GEMM_LIBRARY", mode)
-            o = C0.clone()
-            hip.plain_gemm(A, B, o, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, beta=beta)
-            outs[mode] = o
-            assert nerr(o, ref) < 1e-2, (a_kc, b_kc, beta, mode)
-        assert nerr(outs[True], outs[False]) < 1e-2
-    # not dense (row stride > K) or small: our kernel, whatever the switch says
-    monkeypatch.setattr(hip, "PLAIN_GEMM_LIBRARY", True)
-    Abig = bf(torch.randn(M, K + 64, generator=g)).cuda()
-    W = bf(torch.randn(N, K, generator=g)).cuda()
-    o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    hip.plain_gemm(Abig, W, o, M, N, K, K + 64, K, N)
-    assert nerr(o, Abig[:, :K].float() @ W.float().t()) < 1e-2
-    # a failing library GEMM (e.g. no hipBLASLt for the device) degrades to our kernel, once, with a warning
-    def boom(*a, **k):
-        raise RuntimeError("no library GEMM here")
-    monkeypatch.setattr(torch, "matmul", boom)
-    A = bf(torch.randn(M, K, generator=g)).cuda()
-    with pytest.warns(UserWarning, match="library GEMM failed"):
-        hip.plain_gemm(A, W, o, M, N, K, K, K, N)
-    assert nerr(o, A.float() @ W.float().t()) < 1e-2 and hip.PLAIN_GEMM_LIBRARY is False
+        o = C0.clone()
+        hip.gemm(A, B, o, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, beta=beta)
+        Af, Bf = A.float().cpu(), B.float().cpu()
+        ref = torch.einsum("mk,nk->mn", Af if a_kc else Af.t(), Bf if b_kc else Bf.t()) + beta * C0.float().cpu()
+        assert nerr(o.cpu(), ref) < 1e-2, (a_kc, b_kc, beta)
+    assert not hasattr(hip, "plain_gemm") and not hasattr(hip, "PLAIN_GEMM_LIBRARY")

@@ -40,7 +40,7 @@ def test_eval_metrics_match_reference_golden(golden_dir):
 
 
 def test_tiled_predict_matches_per_tile_forward():
-    from climate_learn.testing import build_pair
+    from oracle.harness import build_pair
     from climate_learn.trainer import clip_replace_constant
     from climate_learn.utils.visualize import tiled_predict, tile_windows
     model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=1, heads=2, grid=(16, 32), B=1, seed=7)
@@ -73,7 +73,7 @@ def test_tiled_predict_matches_per_tile_forward():
 
 def test_visualize_at_index_returns_stitched_north_up_fields(tmp_path):
     import climate_learn as cl
-    from climate_learn.testing import build_pair
+    from oracle.harness import build_pair
     from climate_learn.transforms import Denormalize
     from climate_learn.utils.visualize import visualize_at_index
     model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=1, heads=2, grid=(16, 32), B=1, seed=4)

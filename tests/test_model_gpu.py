@@ -158,14 +158,20 @@ def test_sharded_optimizer_matches_replicated_engine(golden_dir, monkeypatch):
             scl[True].step(opt[True])
             scl[True].update()
             assert torch.equal(a.flat32, b.flat32) and torch.equal(a.flat16, b.flat16), step
-        sa, sb = opt[False].state_dict()["orbit2"], opt[True].state_dict()["orbit2"]
-        assert sa["step"] == sb["step"] == 3 and torch.equal(sa["m"], sb["m"]) and torch.equal(sa["v"], sb["v"])
-        assert float(sa["m"].abs().sum()) > 0
+        sa, sb = opt[False].state_dict(), opt[True].state_dict()
+        assert sa["orbit2"]["step"] == sb["orbit2"]["step"] == 3 and len(sa["state"]) == len(list(a.parameters()))
+        for i in sa["state"]:                        # torch.optim.AdamW's per-parameter format, identical in both modes
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(sa["state"][i][k], sb["state"][i][k]), (i, k)
+        assert sum(float(v["exp_avg"].abs().sum()) for v in sa["state"].values()) > 0
         w = b.module.head[0].weight
         assert torch.equal(w._o2ct, w._o2c.t().contiguous())            # transposed copies follow the gathered copies
         # cross-mode resume
-        opt[True].load_state_dict(opt[False].state_dict())
-        assert torch.equal(opt[True].state_dict()["orbit2"]["m"], sa["m"])
+        keep = dict(sa)
+        opt[True].load_state_dict(sa)
+        assert set(sa) == set(keep)                  # the caller's dict is not mutated
+        sb2 = opt[True].state_dict()
+        assert all(torch.equal(sb2["state"][i]["exp_avg"], sa["state"][i]["exp_avg"]) for i in sa["state"])
         pa, pb = a.state_dict(), b.state_dict()
         assert all(torch.equal(pa[k], pb[k]) for k in pa)
     finally:
@@ -183,7 +189,7 @@ def test_graphed_step_matches_eager_and_draws_new_masks():
     from climate_learn.graphs import GraphedTrainStep, SALT_STEP
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.models.hub.components.vit_blocks import Block
-    from climate_learn.testing import build_pair
+    from oracle.harness import build_pair
     from climate_learn.trainer import training_step
 
     def fresh():
@@ -244,7 +250,7 @@ def test_graphed_step_captures_the_bucket_allreduces(monkeypatch):
     from climate_learn.graphs import GraphedTrainStep, SALT_STEP
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.models.hub.components.vit_blocks import Block
-    from climate_learn.testing import build_pair
+    from oracle.harness import build_pair
     from climate_learn.trainer import training_step
     monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
@@ -296,7 +302,7 @@ def test_train_mode_step_matches_oracle_with_replicated_masks():
     import climate_learn as cl
     from climate_learn import _ops
     from climate_learn.metrics import Bayesian_TV
-    from climate_learn.testing import build_pair, nerr
+    from oracle.harness import build_pair, nerr
     from climate_learn.trainer import training_step
     from tests.hashmask import attn_keep_mask, keep_mask, o2_hash64
     D, depth, heads, grid, B = 128, 3, 2, (16, 32), 2
@@ -362,7 +368,7 @@ def test_train_mode_dropout_and_recompute_match():
     """recompute (activation-checkpoint counterpart) replays the same dropout masks: identical gradients."""
     from climate_learn import manual_seed
     from climate_learn.metrics import Bayesian_TV
-    from climate_learn.testing import build_pair
+    from oracle.harness import build_pair
     from climate_learn.trainer import training_step
     model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2)
     for b in model.blocks:
@@ -392,7 +398,7 @@ def test_train_mode_dropout_and_recompute_match():
 def test_daymet_like_three_outputs_perceptual_loss():
     """SURVEY 8(d) config 5, reduced: V = 7 inputs (4 constants + 3 outputs), C = 3, perceptual loss (seeded stand-in
     LPIPS weights on both sides); loss and gradients through the whole model against the CPU oracle"""
-    from climate_learn.testing import build_pair, nerr
+    from oracle.harness import build_pair, nerr
     from climate_learn.metrics.lpips_hip import LPIPSVGG16
     from climate_learn.trainer import training_step
     outs = ("total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max")
@@ -422,7 +428,7 @@ def test_odd_token_count_grid_trains():
     """a 10 x 20 input grid gives L = 50 tokens per sample (B*L = 150): ragged attention tiles, GEMM rows not a
     multiple of 8 and a weight-gradient contraction that is not a multiple of the k-step; loss + gradients vs the oracle
     (grids stay 2:1 -- the reference's pos-embed resampling assumes it, pos_embed.py:108-111)"""
-    from climate_learn.testing import build_pair, nerr
+    from oracle.harness import build_pair, nerr
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.trainer import training_step
     model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2, grid=(10, 20), B=3, seed=11)
@@ -452,7 +458,7 @@ def test_checkpoint_roundtrip_resumes_identically(tmp_path):
     import climate_learn as cl
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.models.hub.components.vit_blocks import Block
-    from climate_learn.testing import build_pair
+    from oracle.harness import build_pair
     from climate_learn.trainer import training_step
     dev = torch.device("cuda")
     loss_fn = Bayesian_TV(True)

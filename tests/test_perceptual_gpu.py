@@ -130,8 +130,13 @@ def test_perceptual_loss_and_gradient_match_oracle(hip, B, H, W):
     assert rel_l2(pg.grad.cpu() / 3.0, pr.grad) < 5e-2     # 13 bf16 layers deep
 
 
-def test_perceptual_metric_object_and_loader(hip):
+def test_perceptual_metric_object_and_loader(hip, monkeypatch):
     import climate_learn as cl
+    monkeypatch.delenv("ORBIT2_LPIPS_WEIGHTS", raising=False)
+    monkeypatch.delenv("ORBIT2_LPIPS_SYNTHETIC", raising=False)
+    with pytest.raises(RuntimeError, match="ORBIT2_LPIPS_WEIGHTS"):        # never silently train against random LPIPS weights
+        cl.load_loss("cuda", None, "perceptual", True, None)
+    monkeypatch.setenv("ORBIT2_LPIPS_SYNTHETIC", "1")
     loss = cl.load_loss("cuda", None, "perceptual", True, None)
     assert loss.__class__.__name__ == "PERCEPTUAL"
     g = torch.Generator().manual_seed(1)
