@@ -360,6 +360,61 @@ __global__ __launch_bounds__(256, 2) void gemm128_grouped_kernel(GArgs g) {
   gemm128_tile<A_KC, B_KC>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
 }
 
+// epilogue of a 256x256 tile held as 8 waves x (8 x 4) 16x16 accumulators (wave (wm, wn) owns rows wm*128.., columns wn*64..)
+__device__ __forceinline__ void epilogue256(const Epi& epi, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane) {
+  if (epi.out_fp32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        epilogue4(epi, m, n, acc[i][j]);
+      }
+    }
+    return;
+  }
+  // wide path: after the swap of fragments (2jp, 2jp+1), the lane in 16-lane row r4 owns
+  // n = nw + 32*jp + 16*(r4&1) + 8*(r4>>1) + {0..7} of row m
+  const int r4 = lane >> 4;
+  const int nw = n0 + wn * 64 + 16 * (r4 & 1) + 8 * (r4 >> 1);
+  float bias8[2][8];
+  if (epi.bias) {
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int n = nw + 32 * jp;
+      u32x4 b = {0u, 0u, 0u, 0u};
+      if (n < epi.N) b = *reinterpret_cast<const u32x4*>(epi.bias + n);
+      unpack8(b, bias8[jp]);
+    }
+  }
+#pragma unroll
+  for (int ib = 0; ib < 8; ib += 2) {
+    Pre8 q[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+        epi8_load(epi, m0 + wm * 128 + (ib + ii) * 16 + (lane & 15), nw + 32 * jp, q[ii][jp]);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int m = m0 + wm * 128 + (ib + ii) * 16 + (lane & 15);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ib + ii][2 * jp][c]),
+                                                           __float_as_uint(acc[ib + ii][2 * jp + 1][c]), false, false);
+          v[c] = __uint_as_float(sw[0]);
+          v[4 + c] = __uint_as_float(sw[1]);
+        }
+        epi8_finish(epi, m, nw + 32 * jp, v, bias8[jp], q[ii][jp]);
+      }
+    }
+  }
+}
+
 // ==========================================================================================
 // 256x256x32 tile, 512 threads = 8 waves (2x4), wave tile 128x64 (8x4 fragments), 4-stage LDS ring
 // (4 x 32 KiB).  LDS-DMA runs three stages ahead of the MFMAs behind a COUNTED s_waitcnt vmcnt and a raw
@@ -368,6 +423,12 @@ __global__ __launch_bounds__(256, 2) void gemm128_grouped_kernel(GArgs g) {
 //                          f = {0,2,3,1}: conflict-free for the 4x16-lane groups of ds_read_b128.
 //   K-strided operand    : image [32 k][256 cols] (512-B rows), 32-B granule (low 3 bits) ^= (k&3)|((k>>3)&1)<<2.
 // ==========================================================================================
+#ifdef O2_STAMP
+// Diagnostic build only (tools/stamp_build.sh, never the shipped library): waves 0 and 4 of the first 64 workgroups sum
+// the shader cycles they spend in each segment of the main loop; nothing in the kernel reads these words.
+__device__ unsigned int o2_dbg[64 * 2 * 8];
+#define O2_T() ((unsigned)__builtin_amdgcn_s_memtime())
+#endif
 constexpr int BM2 = 256, BN2 = 256, BK2 = 32;
 constexpr int STAGE2 = 2 * 256 * 32 * 2;  // A + B, 32 KiB
 constexpr int NSTAGE2 = 4;
@@ -475,6 +536,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wave >= 4) __builtin_amdgcn_s_barrier();   // stagger the second wave of every SIMD by one phase
+#ifdef O2_STAMP
+  unsigned tL = 0, tBa = 0, tM = 0, tV = 0, tBb = 0, t0 = O2_T(), t1;
+  const unsigned tstart = t0;
+#define O2_SEG(acc) { t1 = O2_T(); acc += t1 - t0; t0 = t1; }
+#else
+#define O2_SEG(acc)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const char* sa = smem + (kt & 3) * STAGE2;
     const char* sb = sa + STAGE2 / 2;
@@ -485,7 +553,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa[i] = read_frag2<A_KC>(sa, wm * 128 + i * 16, lane);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    O2_SEG(tL)
     __builtin_amdgcn_s_barrier();
+    O2_SEG(tBa)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -501,63 +571,197 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    O2_SEG(tM)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    O2_SEG(tV)
     __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
+#ifdef O2_STAMP
+  if (blockIdx.x < 64 && (wave & 3) == 0 && lane == 0) {
+    unsigned* d = o2_dbg + (blockIdx.x * 2 + (wave >> 2)) * 8;
+    d[0] = tL; d[1] = tBa; d[2] = tM; d[3] = tV; d[4] = tBb; d[5] = O2_T() - tstart; d[6] = (unsigned)nk; d[7] = 0;
+  }
+#endif
 
-  if (epi.out_fp32) {
+  epilogue256(epi, acc, m0, n0, wm, wn, lane);
+}
+
+// ==========================================================================================
+// 256x256x64 tile, 512 threads = 8 waves (2 x 4, wave tile 128 x 64), K-contiguous (NT) operands.  Eight phases per
+// two K-tiles: a phase = one 64 x 32 quadrant of the wave tile over a 64-deep K-tile = 16 MFMAs, fed by 0 / 4 / 8 / 12
+// ds_read_b128, with ONE 16-KiB "unit" of a later K-tile put in flight by LDS-DMA (two 1-KiB pieces per wave).
+//   * 64-deep K-tiles: every LDS-DMA lane group fetches whole 128-byte lines (the 32-deep ring above fetches half
+//     lines, twice the requests for the same bytes).
+//   * unit = 128 rows x 64 k (128-byte rows, 16-byte chunk c of unit row u stored at c ^ (u & 7): conflict-free for
+//     ds_read_b128).  The rows of a unit are the rows EVERY wave consumes in the same phase:
+//       A-mh (mh = 0, 1): tile rows  wr*128 + mh*64 + [0, 64)  for wr = 0, 1
+//       B-nh (nh = 0, 1): tile cols  wc*64  + nh*32 + [0, 32)  for wc = 0..3
+//     LDS = 2 K-tiles x 4 units = 128 KiB; a unit is re-filled as soon as its last reader has passed.
+//   * schedule of K-tile t (buffer t & 1), phases p0..p3; fragments of B-nh0 stay in registers for p3:
+//       p0: issue A-mh1(t+1) | read A-mh0, B-nh0 | quadrant (0,0)
+//       p1: issue A-mh0(t+2) | read B-nh1        | quadrant (0,1)
+//       p2: issue B-nh0(t+2) | read A-mh1        | quadrant (1,1)
+//       p3: issue B-nh1(t+2) | vmcnt(6)          | quadrant (1,0)
+//     Every phase is  L: issue + reads + lgkmcnt(0) | s_barrier | M: 16 MFMAs | s_barrier ; waves 4-7 run one barrier
+//     behind waves 0-3, so on every SIMD one wave is in M while its partner is in L.
+//   * hazards.  RAW: the vmcnt(6) in L(t,p3) leaves the three youngest units (issued in p1..p3: K-tile t+2's) in flight, so
+//     every unit of K-tile t+1 (the youngest of them issued in p0) has landed for this wave; both wave groups pass that
+//     wait before the barrier that ends M(t,p3) of waves 0-3, and the first read of K-tile t+1 is in L(t+1,p0), after it.
+//     WAR: a unit is re-filled one phase or more after its last read (A-mh1: read p2 / issued p0 of the next K-tile,
+//     A-mh0: p0 / p1, B-nh0: p0 / p2, B-nh1: p1 / p3), and every wave retires its reads (lgkmcnt(0)) BEFORE the barrier
+//     that ends its L: the other group's issue comes at least one barrier later.
+//   K-tiles past the end re-load the last one into a slot nobody reads again: branch-free loop, constant vmcnt arithmetic.
+// ==========================================================================================
+constexpr int BK3 = 64;
+constexpr int UNIT3 = 128 * 64 * 2;   // 16 KiB
+
+// which: 0 = A-mh0, 1 = A-mh1 (rows of A), 2 = B-nh0, 3 = B-nh1 (rows of B = columns of the output)
+__device__ __forceinline__ void stage_unit3(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int which,
+                                            char* unit, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-        epilogue4(epi, m, n, acc[i][j]);
-      }
-    }
-    return;
+  for (int t = 0; t < 2; ++t) {
+    const int i = wave * 2 + t;               // 1-KiB piece 0..15 of the unit: unit rows 8i .. 8i+7
+    const int u = i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (u & 7);
+    const int h = which & 1;
+    const int trow = which < 2 ? ((u >> 6) * 128 + h * 64 + (u & 63)) : ((u >> 5) * 64 + h * 32 + (u & 31));
+    int gr = r0 + trow;
+    gr = gr < rmax ? gr : rmax - 1;
+    glds16(G + (size_t)gr * ld + k0 + chunk * 8, unit + i * 1024);
   }
-  // wide path: after the swap of fragments (2jp, 2jp+1), the lane in 16-lane row r4 owns
-  // n = nw + 32*jp + 16*(r4&1) + 8*(r4>>1) + {0..7} of row m
-  const int r4 = lane >> 4;
-  const int nw = n0 + wn * 64 + 16 * (r4 & 1) + 8 * (r4 >> 1);
-  float bias8[2][8];
-  if (epi.bias) {
+}
+
+__device__ __forceinline__ bf16x8 read_frag3(const char* unit, int ubase, int kk, int lane) {
+  const int u = ubase + (lane & 15);
+  const int c = kk * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(unit + u * 128 + ((c ^ (u & 7)) << 4));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                          int M, int N, int K, int lda, int ldb, int tiles_m,
+                                                          int tiles_n, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * UNIT3];   // [K-tile parity][A-mh0 | A-mh1 | B-nh0 | B-nh1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  constexpr int GROUP = 2;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsz;
+  const int tn = (id % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  f32x4 acc[8][4];
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      const int n = nw + 32 * jp;
-      u32x4 b = {0u, 0u, 0u, 0u};
-      if (n < epi.N) b = *reinterpret_cast<const u32x4*>(epi.bias + n);
-      unpack8(b, bias8[jp]);
-    }
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK3;
+  auto issue = [&](int t, int which) {
+    const int kt = t < nk ? t : nk - 1;
+    char* unit = smem + ((t & 1) * 4 + which) * UNIT3;
+    if (which < 2) stage_unit3(A, lda, m0, M, kt * BK3, which, unit, wave, lane);
+    else stage_unit3(B, ldb, n0, N, kt * BK3, which, unit, wave, lane);
+  };
+  issue(0, 0); issue(0, 2); issue(0, 3); issue(0, 1);
+  issue(1, 0); issue(1, 2); issue(1, 3);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+#ifdef O2_STAMP
+  unsigned tL = 0, tBa = 0, tM = 0, tV = 0, tBb = 0, t0 = O2_T(), t1;
+  const unsigned tstart = t0;
+#endif
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define O2_MFMA_Q(MI, NJ, FB)                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                           \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+    acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+  for (int t = 0; t < nk; ++t) {
+    const char* ub = smem + (t & 1) * 4 * UNIT3;
+    // ---- p0
+    issue(t + 1, 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = read_frag3(ub + 2 * UNIT3, wn * 32 + j * 16, kk, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag3(ub, wm * 64 + i * 16, kk, lane);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    O2_SEG(tL)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBa)
+    O2_MFMA_Q(0, 0, fb0)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+    // ---- p1
+    issue(t + 2, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = read_frag3(ub + 3 * UNIT3, wn * 32 + j * 16, kk, lane);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    O2_SEG(tL)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBa)
+    O2_MFMA_Q(0, 2, fb1)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+    // ---- p2
+    issue(t + 2, 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag3(ub + UNIT3, wm * 64 + i * 16, kk, lane);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    O2_SEG(tL)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBa)
+    O2_MFMA_Q(4, 2, fb1)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+    // ---- p3
+    issue(t + 2, 3);
+    O2_SEG(tL)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    O2_SEG(tV)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBa)
+    O2_MFMA_Q(4, 0, fb0)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
   }
-#pragma unroll
-  for (int ib = 0; ib < 8; ib += 2) {
-    Pre8 q[2][2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp)
-        epi8_load(epi, m0 + wm * 128 + (ib + ii) * 16 + (lane & 15), nw + 32 * jp, q[ii][jp]);
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int m = m0 + wm * 128 + (ib + ii) * 16 + (lane & 15);
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        float v[8];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ib + ii][2 * jp][c]),
-                                                           __float_as_uint(acc[ib + ii][2 * jp + 1][c]), false, false);
-          v[c] = __uint_as_float(sw[0]);
-          v[4 + c] = __uint_as_float(sw[1]);
-        }
-        epi8_finish(epi, m, nw + 32 * jp, v, bias8[jp], q[ii][jp]);
-      }
-    }
+#undef O2_MFMA_Q
+  if (wave < 4) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
+#ifdef O2_STAMP
+  if (blockIdx.x < 64 && (wave & 3) == 0 && lane == 0) {
+    unsigned* d = o2_dbg + (blockIdx.x * 2 + (wave >> 2)) * 8;
+    d[0] = tL; d[1] = tBa; d[2] = tM; d[3] = tV; d[4] = tBb; d[5] = O2_T() - tstart; d[6] = (unsigned)nk; d[7] = 1;
   }
+#endif
+  epilogue256(epi, acc, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -664,6 +868,12 @@ O2_DEFINE_SALT_OP(gemm)
 
 extern "C" int orbit2_abi_version(void) { return ORBIT2_ABI_VERSION; }
 
+#ifdef O2_STAMP
+extern "C" int orbit2_debug_read(unsigned int* host_dst, int n) {   // diagnostic build only
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(o2_dbg), sizeof(unsigned) * (size_t)n);
+}
+#endif
+
 static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (!a || !a->A || !a->B || !a->C) return O2_ERR_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return O2_ERR_ARG;
@@ -675,6 +885,7 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
       a->ldc % 4)
     return O2_ERR_ARG;
   if (a->tile_hint == 256 && a->K % BK2) return O2_ERR_ARG;
+  if (a->tile_hint == 257 && (a->K % BK3 || !a->a_kc || !a->b_kc)) return O2_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
@@ -732,7 +943,7 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   // (2 workgroups/CU) takes small or ragged problems.  tile_hint forces one (tests / tuning).
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
-  if (tile != 128 && tile != 256) {
+  if (tile != 128 && tile != 256 && tile != 257) {
     // measured on MI355X (tools/gemm_bench.py, interm_1b shapes, random data, profiles/r01_gemm_bench_shapes.txt):
     // the staggered ring kernel wins for the K-contiguous (NT) form whenever it can fill the chip; the 128^2
     // kernel (2 workgroups/CU) wins for both K-strided forms and for small / ragged problems.
@@ -740,6 +951,16 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
     const double util = (double)t256 / (double)(rounds * 256);
     const bool nt = a->a_kc && a->b_kc;
     tile = (nt && a->K % BK2 == 0 && a->M >= 256 && a->N >= 256 && t256 >= 192 && util >= 0.70) ? 256 : 128;
+    // 64-deep K-tiles (8-phase kernel): bit-identical results, 8-15 % faster than the 32-deep ring on the interm_1b
+    // shapes (tools/gemm_p8_ab.py, profiles/r02_gemm_p8_ab.txt); needs K % 64 == 0 and at least two K-tiles
+    if (tile == 256 && a->K % BK3 == 0 && a->K >= 2 * BK3) tile = 257;
+  }
+  if (tile == 257) {
+    const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
+    hipLaunchKernelGGL(gemm256p_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                       tiles_m, tiles_n, e);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
   }
   if (tile == 256) {
     const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
