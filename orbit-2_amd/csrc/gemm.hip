@@ -360,29 +360,33 @@ __global__ __launch_bounds__(256, 2) void gemm128_grouped_kernel(GArgs g) {
   gemm128_tile<A_KC, B_KC>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
 }
 
-// epilogue of a 256x256 tile held as 8 waves x (8 x 4) 16x16 accumulators (wave (wm, wn) owns rows wm*128.., columns wn*64..)
+// epilogue of a 256x256 tile held as 8 waves x (8 x 4) 16x16 accumulators.  Wave (wm, wn) owns the rows
+// wm*MW + (i>>2)*MH + (i&3)*16 (+16) of fragment row i and the columns wn*NW + (j>>1)*NH + (j&1)*16 (+16) of fragment column j:
+//   MW 128, MH 64, NW 64, NH 32 : a contiguous 128 x 64 wave tile (ring kernel, 8-phase NT kernel)
+//   MW 64, MH 128, NW 32, NH 128: two 64-row / 32-column groups half a tile apart (8-phase kernel with contiguous units)
+template <int MW = 128, int MH = 64, int NW = 64, int NH = 32>
 __device__ __forceinline__ void epilogue256(const Epi& epi, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane) {
   if (epi.out_fp32) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+      const int m = m0 + wm * MW + (i >> 2) * MH + (i & 3) * 16 + (lane & 15);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        const int n = n0 + wn * NW + (j >> 1) * NH + (j & 1) * 16 + 4 * (lane >> 4);
         epilogue4(epi, m, n, acc[i][j]);
       }
     }
     return;
   }
   // wide path: after the swap of fragments (2jp, 2jp+1), the lane in 16-lane row r4 owns
-  // n = nw + 32*jp + 16*(r4&1) + 8*(r4>>1) + {0..7} of row m
+  // n = nw + NH*jp + 16*(r4&1) + 8*(r4>>1) + {0..7} of row m
   const int r4 = lane >> 4;
-  const int nw = n0 + wn * 64 + 16 * (r4 & 1) + 8 * (r4 >> 1);
+  const int nw = n0 + wn * NW + 16 * (r4 & 1) + 8 * (r4 >> 1);
   float bias8[2][8];
   if (epi.bias) {
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      const int n = nw + 32 * jp;
+      const int n = nw + NH * jp;
       u32x4 b = {0u, 0u, 0u, 0u};
       if (n < epi.N) b = *reinterpret_cast<const u32x4*>(epi.bias + n);
       unpack8(b, bias8[jp]);
@@ -395,10 +399,10 @@ __device__ __forceinline__ void epilogue256(const Epi& epi, f32x4 (&acc)[8][4], 
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp)
-        epi8_load(epi, m0 + wm * 128 + (ib + ii) * 16 + (lane & 15), nw + 32 * jp, q[ii][jp]);
+        epi8_load(epi, m0 + wm * MW + ((ib + ii) >> 2) * MH + ((ib + ii) & 3) * 16 + (lane & 15), nw + NH * jp, q[ii][jp]);
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
-      const int m = m0 + wm * 128 + (ib + ii) * 16 + (lane & 15);
+      const int m = m0 + wm * MW + ((ib + ii) >> 2) * MH + ((ib + ii) & 3) * 16 + (lane & 15);
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         float v[8];
@@ -409,7 +413,7 @@ __device__ __forceinline__ void epilogue256(const Epi& epi, f32x4 (&acc)[8][4], 
           v[c] = __uint_as_float(sw[0]);
           v[4 + c] = __uint_as_float(sw[1]);
         }
-        epi8_finish(epi, m, nw + 32 * jp, v, bias8[jp], q[ii][jp]);
+        epi8_finish(epi, m, nw + NH * jp, v, bias8[jp], q[ii][jp]);
       }
     }
   }
@@ -764,6 +768,198 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const bf16_t* __restri
   epilogue256(epi, acc, m0, n0, wm, wn, lane);
 }
 
+// ==========================================================================================
+// The same 8-phase schedule for the forms with a K-STRIDED operand (weight gradients dW = dY^T.X: both operands;
+// input gradients dX = dY.W on the stored weight: B).  A K-strided operand is fetched as rows of k, so a unit must be
+// 128 CONTIGUOUS columns (whole 256-byte pieces per k row): unit h of an operand = tile rows / columns h*128 + [0, 128),
+// image [64 k][128 cols] with the 128-tile kernel's granule swizzle, fragments by ds_read_b64_tr_b16.  Wave (wm, wn)
+// therefore owns rows h*128 + wm*64 + [0, 64) and columns h*128 + wn*32 + [0, 32) of BOTH halves h (epilogue256<64, 128, 32,
+// 128>).  K-contiguous operands use the same row sets with the [128 rows][64 k] image of the NT kernel.
+// Schedule as above except that fragment reads stay IN FLIGHT across the barrier that ends L (their latency hides behind
+// the barrier's; the wait sits in front of the first MFMA): a unit may then only be re-filled TWO phases after its last
+// read (the other wave group retires its reads one barrier later), which the order
+//   p0: issue A-h1(t+1) | p1: issue B-h0(t+2) | p2: issue A-h0(t+2) | p3: issue B-h1(t+2)
+// satisfies for all but B-h0 (read p0, re-filled p1): p0 therefore issues its B reads first and retires them -- only
+// them -- with a counted lgkmcnt before its barrier.
+// ==========================================================================================
+template <bool KC>
+__device__ __forceinline__ void stage_unit4(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int h,
+                                            char* unit, int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = wave * 2 + t;               // 1-KiB piece 0..15 of the unit
+    if (KC) {
+      const int u = i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (u & 7);
+      int gr = r0 + h * 128 + u;
+      gr = gr < rmax ? gr : rmax - 1;
+      glds16(G + (size_t)gr * ld + k0 + chunk * 8, unit + i * 1024);
+    } else {
+      const int krow = i * 4 + (lane >> 4);
+      const int cp = lane & 15;
+      const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int chunk = ((((cp >> 1) ^ sw)) << 1) | (cp & 1);
+      int col = r0 + h * 128 + chunk * 8;
+      col = col <= rmax - 8 ? col : rmax - 8;
+      glds16(G + (size_t)(k0 + krow) * ld + col, unit + i * 1024);
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag4(const char* unit, int ubase, int kk, int lane) {
+  if (KC) return read_frag3(unit, ubase, kk, lane);
+  return read_frag<false>(unit, ubase, kk, lane);
+}
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm256t_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
+                                              int K, int lda, int ldb, int tiles_m, int tiles_n, const Epi& epi, int id,
+                                              char* smem) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int GROUP = 4;                       // an XCD's 32 concurrent tiles: 4 tile rows x 8 tile columns
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsz;
+  const int tn = (id % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK3;
+  auto issue = [&](int t, int which) {           // which: 0 = A half 0, 1 = A half 1, 2 = B half 0, 3 = B half 1
+    const int kt = t < nk ? t : nk - 1;
+    char* unit = smem + ((t & 1) * 4 + which) * UNIT3;
+    if (which < 2) stage_unit4<A_KC>(A, lda, m0, M, kt * BK3, which, unit, wave, lane);
+    else stage_unit4<B_KC>(B, ldb, n0, N, kt * BK3, which - 2, unit, wave, lane);
+  };
+  issue(0, 0); issue(0, 2); issue(0, 3); issue(0, 1);
+  issue(1, 2); issue(1, 0); issue(1, 3);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+#ifdef O2_STAMP
+  unsigned tL = 0, tBa = 0, tM = 0, tV = 0, tBb = 0, t0 = O2_T(), t1;
+  const unsigned tstart = t0;
+#endif
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define O2_MFMA_Q(MI, NJ, FB)                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                           \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+    acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+  for (int t = 0; t < nk; ++t) {
+    const char* ub = smem + (t & 1) * 4 * UNIT3;
+    // ---- p0
+    issue(t + 1, 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = read_frag4<B_KC>(ub + 2 * UNIT3, wn * 32 + j * 16, kk, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag4<A_KC>(ub, wm * 64 + i * 16, kk, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // LDS reads return in order: all but the A reads (8 ds_read_b128, or 16 transposing reads -- 15 is the counter's
+    // largest encodable value) have landed = every B-nh0 read, the unit that p1 re-fills
+    __builtin_amdgcn_s_waitcnt(A_KC ? 0xC87F : 0xCF7F);
+    O2_SEG(tL)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    O2_SEG(tBa)
+    O2_MFMA_Q(0, 0, fb0)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+    // ---- p1
+    issue(t + 2, 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = read_frag4<B_KC>(ub + 3 * UNIT3, wn * 32 + j * 16, kk, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    O2_SEG(tL)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    O2_SEG(tBa)
+    O2_MFMA_Q(0, 2, fb1)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+    // ---- p2
+    issue(t + 2, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag4<A_KC>(ub + UNIT3, wm * 64 + i * 16, kk, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    O2_SEG(tL)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    O2_SEG(tBa)
+    O2_MFMA_Q(4, 2, fb1)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+    // ---- p3
+    issue(t + 2, 3);
+    O2_SEG(tL)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    O2_SEG(tV)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBa)
+    O2_MFMA_Q(4, 0, fb0)
+    O2_SEG(tM)
+    __builtin_amdgcn_s_barrier();
+    O2_SEG(tBb)
+  }
+#undef O2_MFMA_Q
+  if (wave < 4) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
+#ifdef O2_STAMP
+  if (blockIdx.x < 64 && (wave & 3) == 0 && lane == 0) {
+    unsigned* d = o2_dbg + (blockIdx.x * 2 + (wave >> 2)) * 8;
+    d[0] = tL; d[1] = tBa; d[2] = tM; d[3] = tV; d[4] = tBb; d[5] = O2_T() - tstart; d[6] = (unsigned)nk; d[7] = 2;
+  }
+#endif
+  epilogue256<64, 128, 32, 128>(epi, acc, m0, n0, wm, wn, lane);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm256t_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                          int M, int N, int K, int lda, int ldb, int tiles_m,
+                                                          int tiles_n, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * UNIT3];
+  gemm256t_tile<A_KC, B_KC>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+}
+
+// grouped form (the four weight gradients of a Block in one grid: 144 + 432 + 576 + 576 tiles fill 6.75 rounds of the 256
+// CUs instead of 0.56 + 1.69 + 2.25 + 2.25 one by one)
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm256t_grouped_kernel(GArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * UNIT3];
+  const int id = xcd_tile_id();
+  int pi = 0;
+  while (pi + 1 < g.n && id >= g.p[pi].tile_end) ++pi;
+  const int first = pi ? g.p[pi - 1].tile_end : 0;
+  const GProb& P = g.p[pi];
+  const Epi epi = P.epi;
+  gemm256t_tile<A_KC, B_KC>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // small fp32 GEMM (table algebra; sizes ~ [115 x D] x [D x D]): 64x64 tile, 16x16 threads, 4x4 micro-tile
 // ------------------------------------------------------------------------------------------
@@ -886,6 +1082,7 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
     return O2_ERR_ARG;
   if (a->tile_hint == 256 && a->K % BK2) return O2_ERR_ARG;
   if (a->tile_hint == 257 && (a->K % BK3 || !a->a_kc || !a->b_kc)) return O2_ERR_ARG;
+  if (a->tile_hint == 258 && (a->K % BK3 || a->M < 8 || a->N < 8)) return O2_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
@@ -909,6 +1106,16 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
   if (n == 1) return orbit2_gemm_bf16(args, stream);
   GArgs g;
   g.n = n;
+  // 256-tile 8-phase kernel when every problem of the group can take it and the group fills the chip; 128-tile otherwise
+  bool big = args[0].tile_hint != 128;
+  long t256 = 0;
+  for (int i = 0; i < n; ++i) {
+    const orbit2_gemm_args* a = args + i;
+    if (a->K % BK3 || a->K < 2 * BK3 || a->M < 256 || a->N < 256) big = false;
+    t256 += (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+  }
+  if (args[0].tile_hint != 258 && t256 < 192) big = false;
+  const int TB = big ? 256 : 128;
   int total = 0;
   for (int i = 0; i < n; ++i) {
     const orbit2_gemm_args* a = args + i;
@@ -918,12 +1125,21 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
     GProb& P = g.p[i];
     P.A = (const bf16_t*)a->A; P.B = (const bf16_t*)a->B;
     P.M = a->M; P.N = a->N; P.K = a->K; P.lda = a->lda; P.ldb = a->ldb;
-    P.tiles_m = (a->M + BM - 1) / BM; P.tiles_n = (a->N + BN - 1) / BN;
+    P.tiles_m = (a->M + TB - 1) / TB; P.tiles_n = (a->N + TB - 1) / TB;
     total += P.tiles_m * P.tiles_n;
     P.tile_end = total;
   }
-  dim3 grid(total), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (big) {
+    dim3 grid(total), block(512);
+    if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm256t_grouped_kernel<true, true>), grid, block, 0, s, g);
+    else if (args[0].a_kc) hipLaunchKernelGGL((gemm256t_grouped_kernel<true, false>), grid, block, 0, s, g);
+    else if (args[0].b_kc) hipLaunchKernelGGL((gemm256t_grouped_kernel<false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm256t_grouped_kernel<false, false>), grid, block, 0, s, g);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
+  }
+  dim3 grid(total), block(256);
   if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm128_grouped_kernel<true, true>), grid, block, 0, s, g);
   else if (args[0].a_kc) hipLaunchKernelGGL((gemm128_grouped_kernel<true, false>), grid, block, 0, s, g);
   else if (args[0].b_kc) hipLaunchKernelGGL((gemm128_grouped_kernel<false, true>), grid, block, 0, s, g);
@@ -943,7 +1159,7 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   // (2 workgroups/CU) takes small or ragged problems.  tile_hint forces one (tests / tuning).
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
-  if (tile != 128 && tile != 256 && tile != 257) {
+  if (tile != 128 && tile != 256 && tile != 257 && tile != 258) {
     // measured on MI355X (tools/gemm_bench.py, interm_1b shapes, random data, profiles/r01_gemm_bench_shapes.txt):
     // the staggered ring kernel wins for the K-contiguous (NT) form whenever it can fill the chip; the 128^2
     // kernel (2 workgroups/CU) wins for both K-strided forms and for small / ragged problems.
@@ -954,6 +1170,24 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
     // 64-deep K-tiles (8-phase kernel): bit-identical results, 8-15 % faster than the 32-deep ring on the interm_1b
     // shapes (tools/gemm_p8_ab.py, profiles/r02_gemm_p8_ab.txt); needs K % 64 == 0 and at least two K-tiles
     if (tile == 256 && a->K % BK3 == 0 && a->K >= 2 * BK3) tile = 257;
+  }
+  if (tile == 258) {
+    const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
+    dim3 grid(tiles_m * tiles_n), block(512);
+    if (a->a_kc && a->b_kc)
+      hipLaunchKernelGGL((gemm256t_kernel<true, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    else if (a->a_kc && !a->b_kc)
+      hipLaunchKernelGGL((gemm256t_kernel<true, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    else if (!a->a_kc && a->b_kc)
+      hipLaunchKernelGGL((gemm256t_kernel<false, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    else
+      hipLaunchKernelGGL((gemm256t_kernel<false, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
+                         tiles_m, tiles_n, e);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
   }
   if (tile == 257) {
     const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
