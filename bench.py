@@ -64,10 +64,11 @@ def parse():
     ap.add_argument("--daymet", action="store_true",
                     help="BASELINE configs[4] / SURVEY 8d-5: 7 Daymet-like inputs, 3 outputs, hybrid perceptual loss "
                          "(use --grid 96x192); not the headline configuration")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay zero_grad+forward+loss+backward (+bucket all-reduces) from one captured hipGraph "
-                         "(launch-bound small configurations); the roofline fields then come from an eager "
-                         "instrumented pass")
+    ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="replay zero_grad+forward+loss+backward (+bucket all-reduces) from one captured hipGraph; auto "
+                         "(default): on when a step has <= 16384 tokens per GPU (launch-bound small configurations), off "
+                         "for the GPU-bound headline configuration, whose kernels are then timed with HIP events inside "
+                         "the timed region; with the graph on the roofline fields come from an eager instrumented pass")
     ap.add_argument("--tensor-par", type=int, default=1,
                     help="head-split tensor parallelism over adjacent ranks (DESIGN 5c); WORLD_SIZE = dp x tp, the "
                          "reported value counts dp x batch samples per step")
@@ -288,6 +289,8 @@ def main():
     L = h * w // 4
     drop = 0.0 if a.no_dropout else 0.1
     tp = a.tensor_par
+    capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
+    a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable)
     if tp > 1 and (world % tp or a.graph):
         raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)
     dp_world, dp_rank = world // tp, rank // tp

@@ -173,6 +173,15 @@ def main():
         in_shape, _ = dm.get_data_dims()
         eng.data_config(dc["spatial_resolution"][data_key], tuple(in_shape[2:]), len(in_vars), len(out_vars))
         var_weights = dc.get("var_weights", {})
+        # hipGraph replay of zero_grad + forward + loss + backward (climate_learn/graphs.py) for the launch-bound
+        # configurations: `trainer.hipgraph: auto` (default) turns it on when a step has few tokens (<= 16384: the 32x64-grid
+        # presets; interm_1b-class steps are GPU-bound and stay eager), true / false force it.  Batches of another shape than
+        # the captured one (the short last batch of an epoch) run eagerly.
+        hg = tr.get("hipgraph", "auto")
+        tokens = batch_size * (in_shape[2] // mc["patch_size"]) * (in_shape[3] // mc["patch_size"])
+        capturable = world_size == 1 or dist.get_backend() == "nccl"      # gloo rehearsals stage through the host: no capture
+        use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable)) and tp == 1
+        gstep, gshape = None, None
         for epoch in range(epoch_start, max_epochs):
             eng.train()
             epoch_loss = torch.zeros((), dtype=torch.float32, device=device)
@@ -182,18 +191,32 @@ def main():
                 if world_rank == 0:
                     torch.cuda.synchronize(device)
                     tic1 = time.perf_counter()
-                loss = training_step(batch, batch_idx, eng, device, var_weights, train_loss)
-                epoch_loss += loss.detach()
-                if world_rank == 0:
-                    print("epoch: ", epoch, "batch_idx", batch_idx, "world_rank", world_rank, " loss ", float(loss), flush=True)
-                optimizer.zero_grad()
-                if scaler is None:
-                    loss.backward()
-                    optimizer.step()
+                shape = (tuple(batch[0].shape), tuple(batch[1].shape))
+                if use_graph and (gstep is None or shape == gshape):
+                    if gstep is None:
+                        gstep, gshape = cl.GraphedTrainStep(eng, train_loss, batch, var_weights, scaler=scaler), shape
+                    loss = gstep(batch)
+                    epoch_loss += loss
+                    if world_rank == 0:
+                        print("epoch: ", epoch, "batch_idx", batch_idx, "world_rank", world_rank, " loss ", float(loss), flush=True)
+                    if scaler is None:
+                        optimizer.step()
+                    else:
+                        scaler.step(optimizer)
+                        scaler.update()
                 else:
-                    scaler.scale(loss).backward()
-                    scaler.step(optimizer)
-                    scaler.update()
+                    loss = training_step(batch, batch_idx, eng, device, var_weights, train_loss)
+                    epoch_loss += loss.detach()
+                    if world_rank == 0:
+                        print("epoch: ", epoch, "batch_idx", batch_idx, "world_rank", world_rank, " loss ", float(loss), flush=True)
+                    optimizer.zero_grad()
+                    if scaler is None:
+                        loss.backward()
+                        optimizer.step()
+                    else:
+                        scaler.scale(loss).backward()
+                        scaler.step(optimizer)
+                        scaler.update()
                 if world_rank == 0:
                     torch.cuda.synchronize(device)
                     print("rank", world_rank, "batch_idx", batch_idx, "get_lr ", scheduler.get_last_lr(),

@@ -49,12 +49,13 @@ typedef struct {
   int ldr, res_mod, res_first;
   int out_fp32;            /* 0: C is bf16, 1: C is fp32 */
   float beta;              /* C = beta*C + result (gradient accumulation) */
-  int tile_hint;           /* 0 = auto, 128 or 256 = force that kernel (tests / tuning) */
+  int tile_hint;           /* 0 = auto, 128 or 256 = force that kernel (tests / tuning; 256 needs K % 64 == 0) */
 } orbit2_gemm_args;
 int orbit2_gemm_bf16(const orbit2_gemm_args* args, void* stream);
 
-/* n (<= ORBIT2_GEMM_MAX_GROUP) independent problems of ONE operand form (same a_kc, b_kc) in one launch of the
- * 128x128 kernel: the partially filled last round of each problem is filled with the next one's tiles.  Used for
+/* n (<= ORBIT2_GEMM_MAX_GROUP) independent problems of ONE operand form (same a_kc, b_kc) in one launch (the 256x256
+ * 8-phase kernel when every problem has K % 64 == 0, M, N >= 256 and the group fills the chip; the 128x128 kernel
+ * otherwise): the partially filled last round of each problem is filled with the next one's tiles.  Used for
  * the four weight-gradient GEMMs of a Block (reference: autograd of attention.py:36,40 + mlp.py:50,54). */
 #define ORBIT2_GEMM_MAX_GROUP 8
 int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream);

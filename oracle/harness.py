@@ -8,8 +8,10 @@ import numpy as np
 import torch
 
 
-def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_vars=("total_precipitation_24hr",)):
-    """(HIP model on cuda, oracle state dict + config on CPU) holding identical weights + a seeded batch."""
+def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_vars=("total_precipitation_24hr",),
+               in_vars=None):
+    """(HIP model on cuda, oracle state dict + config on CPU) holding identical weights + a seeded batch.
+    in_vars: the input variable list (default: the four constants + the output variables)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "orbit-2_amd")):
         if p not in sys.path:
@@ -17,7 +19,7 @@ def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_va
     from oracle import orbit2_oracle as O
     from climate_learn.models.hub import Res_Slim_ViT
     consts = ["land_sea_mask", "orography", "lattitude", "landcover"]
-    in_vars = consts + [v for v in out_vars]
+    in_vars = list(in_vars) if in_vars is not None else consts + [v for v in out_vars]
     cfg = O.Config(in_vars, grid, len(out_vars), D, depth, dd, heads, spatial_resolution=156.0)
     sd = O.init_state_dict(cfg, len(in_vars), seed=seed)
     g = torch.Generator().manual_seed(seed + 1)

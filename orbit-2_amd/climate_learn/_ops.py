@@ -111,12 +111,10 @@ def _linear_fwd(x2d, W, b, M, N, K, **kw):
 
 
 def _dx(dy2d, W, M, N, K, **kw):
-    """dx[M,K] = dy[M,N] . W[N,K].  With an engine-maintained transposed compute copy W^T [K,N] the GEMM runs in
-    the K-contiguous form (faster kernel); otherwise W is read through the hardware-transposing LDS path."""
+    """dx[M,K] = dy[M,N] . W[N,K] on the weight AS STORED: W is the K-strided operand, read through the
+    hardware-transposing LDS path of the 8-phase kernel (as fast as the K-contiguous form on a transposed copy --
+    profiles/r02_gemm_t8_ab.txt -- so the per-step transposed weight copies of round 1 are gone)."""
     out = torch.empty(M, K, dtype=BF, device=dy2d.device)
-    wt = getattr(W, "_o2ct", None)
-    if wt is not None:
-        return _hip.gemm(dy2d, wt, out, M, K, N, N, N, K, a_kc=True, b_kc=True, **kw)
     return _hip.gemm(dy2d, cw(W), out, M, K, N, N, K, K, a_kc=True, b_kc=False, **kw)
 
 

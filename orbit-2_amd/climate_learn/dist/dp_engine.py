@@ -70,7 +70,7 @@ class Bucket:
 class HipDataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (),
                  is_lowp=None, sync_module_states: bool = True, overlap: bool = True,
-                 transposed_copies: bool = True, shard_optimizer: bool = False, replica_group=None):
+                 shard_optimizer: bool = False, replica_group=None):
         """replica_group: the tensor-parallel group of this rank (dist/tp.py).  The parameters that are NOT split
         over it are replicas whose gradients agree only up to the summation order of the few atomic reductions
         (conv weight gradients, variable-aggregation tables) -- and AdamW turns an ulp of difference in a near-zero
@@ -119,7 +119,6 @@ class HipDataParallel(nn.Module):
         self.g32 = torch.zeros(max(ng32, 1), dtype=F32, device=dev)
         # master layout: per unit [lowp params..., fp32-compute params...]; lowp masters of ALL units are also
         # laid out so that flat16/g16 offsets follow the same order -> AdamW runs on (few) long ranges.
-        self._tparams: List[nn.Parameter] = []       # 2-D GEMM weights that keep a transposed bf16 copy
         self.buckets: List[Bucket] = []
         self.lowp_ranges: List[Tuple[int, int, int]] = []   # (off32, off16, n) per unit
         self.hi_ranges: List[Tuple[int, int, int]] = []     # (off32, offg32, n) per unit
@@ -142,9 +141,6 @@ class HipDataParallel(nn.Module):
                 p._o2g = self.g16[o16:o16 + k].view(p.shape)
                 p._o2_fresh = True
                 p._o2_engine = self
-                if transposed_copies and p.dim() == 2 and dev.type == "cuda" and min(p.shape) >= 64:
-                    p._o2ct = torch.empty(p.shape[1], p.shape[0], dtype=BF, device=dev)
-                    self._tparams.append(p)
                 bk.params.append(p)
                 self._bucket_of[id(p)] = bk
                 o32 += _round_up(k)
@@ -210,14 +206,6 @@ class HipDataParallel(nn.Module):
                 _hip.cast_to_bf16(self.flat32[o32:o32 + n], self.flat16[o16:o16 + n])
             else:
                 self.flat16[o16:o16 + n].copy_(self.flat32[o32:o32 + n])
-        self.refresh_transposed_copies()
-
-    def refresh_transposed_copies(self):
-        """W^T bf16 copies (used by the input-gradient GEMMs) follow the compute copies after every update."""
-        if self._tparams:
-            from .. import _hip
-            for p in self._tparams:
-                _hip.transpose_bf16(p._o2c, p._o2ct)
 
     # ---- gradient life cycle ------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):

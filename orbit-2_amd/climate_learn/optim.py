@@ -54,7 +54,6 @@ class HipAdamW(torch.optim.Optimizer):
                     _hip.adamw(e.flat32[o32:], self.m[os_:], self.v[os_:], e.g32[og:], None, n, lr, b1, b2, eps, wd,
                                self._step, gs, fi)
             e.gather_params()
-            e.refresh_transposed_copies()
             return None
         # un-managed parameters (unit tests / tiny models): one launch per tensor
         for group in self.param_groups:

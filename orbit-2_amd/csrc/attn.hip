@@ -19,6 +19,16 @@
 
 namespace {
 
+#ifdef O2_STAMP
+// Diagnostic build only (tools/stamp_build.sh): wave 0 of the first 64 workgroups of the forward / dK kernels sums the shader
+// cycles of each segment of its tile loop; nothing in the kernels reads these words.
+__device__ unsigned int o2_dbg_attn[64 * 8];
+#define O2_T() ((unsigned)__builtin_amdgcn_s_memtime())
+#define O2_SEG(acc) { t1_ = O2_T(); acc += t1_ - t0_; t0_ = t1_; }
+#else
+#define O2_SEG(acc)
+#endif
+
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
   bf16x8 r;
 #pragma unroll
@@ -119,6 +129,10 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+#ifdef O2_STAMP
+  unsigned tS = 0, tQK = 0, tSM = 0, tPV = 0, tW = 0, tB = 0, t0_ = O2_T(), t1_;
+  const unsigned tstart_ = t0_;
+#endif
   for (int t = 0; t < nt; ++t) {
     const char* sk = smem + cur * 2 * C::TILE;
     const char* sv = sk + C::TILE;
@@ -128,6 +142,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
       stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
       if (DROP) stage_keyhash(skh[cur ^ 1], seed, t + 1, tid);
     }
+    O2_SEG(tS)
     // S^T[kb] = K_kb . Q^T   (rows = keys in registers, column = query on the lane)
     f32x16 s[2];
 #pragma unroll
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
         for (int r = 0; r < 16; ++r)
           if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) s[kb][r] = -1e30f;
     }
+    O2_SEG(tQK)
     // online softmax over this lane's query row (its 32 keys + the partner half's 32)
     float mx = -1e30f;
 #pragma unroll
@@ -185,6 +201,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
       for (int kb = 0; kb < 2; ++kb)
         drop_keys_in_regs(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
     }
+    O2_SEG(tSM)
     // O^T[db] += V^T . P^T
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -195,10 +212,19 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
         for (int db = 0; db < C::NDB; ++db)
           o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
       }
+    O2_SEG(tPV)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    O2_SEG(tW)
     __syncthreads();
+    O2_SEG(tB)
     cur ^= 1;
   }
+#ifdef O2_STAMP
+  if (blockIdx.x < 64 && wave == 0 && lane == 0) {
+    unsigned* dd_ = o2_dbg_attn + blockIdx.x * 8;
+    dd_[0] = tS; dd_[1] = tQK; dd_[2] = tSM; dd_[3] = tPV; dd_[4] = tW; dd_[5] = tB; dd_[6] = O2_T() - tstart_; dd_[7] = (unsigned)nt;
+  }
+#endif
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
   if (!q_ok) return;
@@ -555,6 +581,12 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
 }  // namespace
 
 O2_DEFINE_SALT_OP(attn)
+
+#ifdef O2_STAMP
+extern "C" int orbit2_debug_read_attn(unsigned int* host_dst, int n) {   // diagnostic build only
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(o2_dbg_attn), sizeof(unsigned) * (size_t)n);
+}
+#endif
 
 static int attn_check(const void* a, const void* b, int B, int L, int H, int d, float p) {
   if (!a || !b || B <= 0 || L <= 0 || H <= 0) return O2_ERR_ARG;

@@ -419,224 +419,54 @@ __device__ __forceinline__ void epilogue256(const Epi& epi, f32x4 (&acc)[8][4], 
   }
 }
 
-// ==========================================================================================
-// 256x256x32 tile, 512 threads = 8 waves (2x4), wave tile 128x64 (8x4 fragments), 4-stage LDS ring
-// (4 x 32 KiB).  LDS-DMA runs three stages ahead of the MFMAs behind a COUNTED s_waitcnt vmcnt and a raw
-// s_barrier, so global loads stay in flight across barriers (one barrier per 32 MFMAs per wave).
-//   K-contiguous operand : image [256 rows][32 k] (64-B rows), 16-B chunk c stored at c ^ f(row>>2),
-//                          f = {0,2,3,1}: conflict-free for the 4x16-lane groups of ds_read_b128.
-//   K-strided operand    : image [32 k][256 cols] (512-B rows), 32-B granule (low 3 bits) ^= (k&3)|((k>>3)&1)<<2.
-// ==========================================================================================
 #ifdef O2_STAMP
 // Diagnostic build only (tools/stamp_build.sh, never the shipped library): waves 0 and 4 of the first 64 workgroups sum
 // the shader cycles they spend in each segment of the main loop; nothing in the kernel reads these words.
 __device__ unsigned int o2_dbg[64 * 2 * 8];
 #define O2_T() ((unsigned)__builtin_amdgcn_s_memtime())
 #endif
-constexpr int BM2 = 256, BN2 = 256, BK2 = 32;
-constexpr int STAGE2 = 2 * 256 * 32 * 2;  // A + B, 32 KiB
-constexpr int NSTAGE2 = 4;
-
-__device__ __forceinline__ int swz_kc32(int row) {
-  const int q = (row >> 2) & 3;
-  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
-}
-
-template <bool KC>
-__device__ __forceinline__ void stage_tile2(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0,
-                                            char* tile, int wave, int lane) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = wave * 2 + t;  // instruction id 0..15 (1 KiB each) of this 16 KiB operand tile
-    const bf16_t* src;
-    if (KC) {
-      const int row = i * 16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ swz_kc32(row);
-      int gr = r0 + row;
-      gr = gr < rmax ? gr : rmax - 1;
-      src = G + (size_t)gr * ld + k0 + chunk * 8;
-    } else {
-      const int krow = i * 2 + (lane >> 5);
-      const int cp = lane & 31;
-      const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
-      const int gran = cp >> 1;
-      const int chunk = ((((gran & 8) | ((gran & 7) ^ sw))) << 1) | (cp & 1);
-      int col = r0 + chunk * 8;
-      col = col <= rmax - 8 ? col : rmax - 8;
-      src = G + (size_t)(k0 + krow) * ld + col;
-    }
-    glds16(src, tile + i * 1024);
-  }
-}
-
-template <bool KC>
-__device__ __forceinline__ bf16x8 read_frag2(const char* tile, int r0, int lane) {
-  if (KC) {
-    const int row = r0 + (lane & 15);
-    const int chunk = lane >> 4;
-    return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((chunk ^ swz_kc32(row)) << 4));
-  } else {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const int krow = 8 * g + q;
-    const int sw = q | ((g & 1) << 2);
-    const int gran = r0 >> 4;
-    const char* a = tile + krow * 512 + (((gran & 8) | ((gran & 7) ^ sw)) << 5) + 8 * pp;
-    const bf16x4 lo = lds_tr4(a);
-    const bf16x4 hi = lds_tr4(a + 4 * 512);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  }
-}
-
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         int M, int N, int K, int lda, int ldb, int tiles_m,
-                                                         int tiles_n, Epi epi) {
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE2 * STAGE2];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int nwg = gridDim.x;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  constexpr int GROUP = 2;
-  const int per_group = GROUP * tiles_n;
-  const int grp = id / per_group;
-  const int first_m = grp * GROUP;
-  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (id % per_group) % gsz;
-  const int tn = (id % per_group) / gsz;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / BK2;
-  // Ring protocol (4 slots of one 32-deep K-slab each), two barriers per K-slab, the two waves of every SIMD
-  // (wave w and w+4) STAGGERED by one barrier so that one of them issues MFMAs while the other one loads:
-  //   L(kt): refill the slot of stage kt-1 with stage kt+3 (LDS-DMA; half of the pieces are issued between the
-  //          MFMAs of M to balance the two phases), read the 12 fragments of stage kt, lgkmcnt(0)
-  //   M(kt): 32 MFMAs; counted vmcnt(4): stage kt+2 has landed, stage kt+3 stays in flight
-  //   A (waves 0-3):  L(0) | M(0) | L(1) | M(1) | ...        B (waves 4-7):  -- | L(0) | M(0) | L(1) | ...
-  // Hazards (| = s_barrier).  WAR: slot (kt-1)&3 is refilled in L(kt)/M(kt); its last readers are A's L(kt-1) and
-  // B's L(kt-1) (concurrent with A's M(kt-1)), both at least one barrier earlier.  RAW: stage kt is read in L(kt);
-  // every wave waited for its share of it at the end of its M(kt-2), B's M(kt-2) being concurrent with A's
-  // L(kt-1), i.e. one barrier before A's L(kt).
-  // Stages past the end re-load the last K-slab into a dead slot: branch-free loop, constant vmcnt arithmetic.
-  auto issue_a = [&](int st) {
-    const int kst = st < nk ? st : nk - 1;
-    stage_tile2<A_KC>(A, lda, m0, M, kst * BK2, smem + (st & 3) * STAGE2, wave, lane);
-  };
-  auto issue_b = [&](int st) {
-    const int kst = st < nk ? st : nk - 1;
-    stage_tile2<B_KC>(B, ldb, n0, N, kst * BK2, smem + (st & 3) * STAGE2 + STAGE2 / 2, wave, lane);
-  };
-  issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2); issue_b(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wave >= 4) __builtin_amdgcn_s_barrier();   // stagger the second wave of every SIMD by one phase
+constexpr int BM2 = 256, BN2 = 256;
 #ifdef O2_STAMP
-  unsigned tL = 0, tBa = 0, tM = 0, tV = 0, tBb = 0, t0 = O2_T(), t1;
-  const unsigned tstart = t0;
 #define O2_SEG(acc) { t1 = O2_T(); acc += t1 - t0; t0 = t1; }
 #else
 #define O2_SEG(acc)
 #endif
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* sa = smem + (kt & 3) * STAGE2;
-    const char* sb = sa + STAGE2 / 2;
-    bf16x8 fa[8], fb[4];
-    issue_a(kt + 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = read_frag2<B_KC>(sb, wn * 64 + j * 16, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = read_frag2<A_KC>(sa, wm * 128 + i * 16, lane);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    O2_SEG(tL)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBa)
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_b(kt + 3);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 4; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    O2_SEG(tM)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    O2_SEG(tV)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBb)
-  }
-  if (wave < 4) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
-#ifdef O2_STAMP
-  if (blockIdx.x < 64 && (wave & 3) == 0 && lane == 0) {
-    unsigned* d = o2_dbg + (blockIdx.x * 2 + (wave >> 2)) * 8;
-    d[0] = tL; d[1] = tBa; d[2] = tM; d[3] = tV; d[4] = tBb; d[5] = O2_T() - tstart; d[6] = (unsigned)nk; d[7] = 0;
-  }
-#endif
-
-  epilogue256(epi, acc, m0, n0, wm, wn, lane);
-}
 
 // ==========================================================================================
-// 256x256x64 tile, 512 threads = 8 waves (2 x 4, wave tile 128 x 64), K-contiguous (NT) operands.  Eight phases per
-// two K-tiles: a phase = one 64 x 32 quadrant of the wave tile over a 64-deep K-tile = 16 MFMAs, fed by 0 / 4 / 8 / 12
-// ds_read_b128, with ONE 16-KiB "unit" of a later K-tile put in flight by LDS-DMA (two 1-KiB pieces per wave).
-//   * 64-deep K-tiles: every LDS-DMA lane group fetches whole 128-byte lines (the 32-deep ring above fetches half
-//     lines, twice the requests for the same bytes).
-//   * unit = 128 rows x 64 k (128-byte rows, 16-byte chunk c of unit row u stored at c ^ (u & 7): conflict-free for
-//     ds_read_b128).  The rows of a unit are the rows EVERY wave consumes in the same phase:
-//       A-mh (mh = 0, 1): tile rows  wr*128 + mh*64 + [0, 64)  for wr = 0, 1
-//       B-nh (nh = 0, 1): tile cols  wc*64  + nh*32 + [0, 32)  for wc = 0..3
-//     LDS = 2 K-tiles x 4 units = 128 KiB; a unit is re-filled as soon as its last reader has passed.
-//   * schedule of K-tile t (buffer t & 1), phases p0..p3; fragments of B-nh0 stay in registers for p3:
-//       p0: issue A-mh1(t+1) | read A-mh0, B-nh0 | quadrant (0,0)
-//       p1: issue A-mh0(t+2) | read B-nh1        | quadrant (0,1)
-//       p2: issue B-nh0(t+2) | read A-mh1        | quadrant (1,1)
-//       p3: issue B-nh1(t+2) | vmcnt(6)          | quadrant (1,0)
-//     Every phase is  L: issue + reads + lgkmcnt(0) | s_barrier | M: 16 MFMAs | s_barrier ; waves 4-7 run one barrier
-//     behind waves 0-3, so on every SIMD one wave is in M while its partner is in L.
+// 256x256x64 tile, 512 threads = 8 waves (2 x 4), every operand form (NT forward GEMMs, NN input gradients on the stored
+// weight, TN weight gradients).  Eight phases per two K-tiles: a phase = one 64 x 32 quadrant of a wave's 128 x 64
+// accumulators over a 64-deep K-tile = 16 MFMAs, fed by 0 / 4 / 8 / 12 fragment reads, with ONE 16-KiB "unit" of a later
+// K-tile put in flight by LDS-DMA (two 1-KiB pieces per wave).
+//   * 64-deep K-tiles: every LDS-DMA lane group fetches whole 128-byte lines (the 32-deep ring kernel of round 1 fetched
+//     half lines: twice the requests for the same bytes; its stamps -- profiles/r02_gemm_stamps.txt -- also showed the two
+//     LDS-DMA pieces it issued between the MFMAs stretching every 512-cycle MFMA segment to ~685).
+//   * unit h (h = 0, 1) of an operand = tile rows / columns h*128 + [0, 128), 64 k deep.  K-contiguous operand: image
+//     [128 rows][64 k] (128-byte rows, 16-byte chunk c of unit row u stored at c ^ (u & 7): conflict-free ds_read_b128).
+//     K-strided operand (fetched as rows of k, so a unit must be 128 CONTIGUOUS columns = whole 256-byte pieces): image
+//     [64 k][128 cols] with the 128-tile kernel's granule swizzle, fragments by ds_read_b64_tr_b16.
+//     Wave (wm, wn) owns rows h*128 + wm*64 + [0, 64) and columns h*128 + wn*32 + [0, 32) of BOTH halves h, so every wave
+//     consumes a unit in the same phase (epilogue256<64, 128, 32, 128>).  LDS = 2 K-tiles x 4 units = 128 KiB; a unit is
+//     re-filled as soon as its last reader has passed.
+//   * schedule of K-tile t (buffer t & 1); fragments of B-h0 stay in registers for p3:
+//       p0: issue A-h1(t+1) | read B-h0, A-h0 | quadrant (0,0)
+//       p1: issue B-h0(t+2) | read B-h1       | quadrant (0,1)
+//       p2: issue A-h0(t+2) | read A-h1       | quadrant (1,1)
+//       p3: issue B-h1(t+2) | vmcnt(6)        | quadrant (1,0)
+//     Every phase is  L: issue + reads | s_barrier | lgkmcnt(0), M: 16 MFMAs | s_barrier ; waves 4-7 run one barrier behind
+//     waves 0-3, so on every SIMD one wave is in M while its partner is in L.  Fragment reads stay IN FLIGHT across the
+//     barrier that ends L (their latency hides behind the barrier's).
 //   * hazards.  RAW: the vmcnt(6) in L(t,p3) leaves the three youngest units (issued in p1..p3: K-tile t+2's) in flight, so
 //     every unit of K-tile t+1 (the youngest of them issued in p0) has landed for this wave; both wave groups pass that
 //     wait before the barrier that ends M(t,p3) of waves 0-3, and the first read of K-tile t+1 is in L(t+1,p0), after it.
-//     WAR: a unit is re-filled one phase or more after its last read (A-mh1: read p2 / issued p0 of the next K-tile,
-//     A-mh0: p0 / p1, B-nh0: p0 / p2, B-nh1: p1 / p3), and every wave retires its reads (lgkmcnt(0)) BEFORE the barrier
-//     that ends its L: the other group's issue comes at least one barrier later.
+//     WAR: with reads in flight across a barrier the other wave group retires its reads one barrier later, so a unit may
+//     only be re-filled TWO phases after its last read: A-h1 (read p2 / issued p0 of the next K-tile), A-h0 (p0 / p2),
+//     B-h1 (p1 / p3) keep that distance; B-h0 (read p0, re-filled p1) does not, so p0 issues its B reads FIRST and retires
+//     them -- only them -- with a counted lgkmcnt before its barrier (LDS reads return in order).
 //   K-tiles past the end re-load the last one into a slot nobody reads again: branch-free loop, constant vmcnt arithmetic.
+//   Results are bit-identical to the 128-tile kernel's (same k order per accumulator).
 // ==========================================================================================
 constexpr int BK3 = 64;
 constexpr int UNIT3 = 128 * 64 * 2;   // 16 KiB
-
-// which: 0 = A-mh0, 1 = A-mh1 (rows of A), 2 = B-nh0, 3 = B-nh1 (rows of B = columns of the output)
-__device__ __forceinline__ void stage_unit3(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int which,
-                                            char* unit, int wave, int lane) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = wave * 2 + t;               // 1-KiB piece 0..15 of the unit: unit rows 8i .. 8i+7
-    const int u = i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (u & 7);
-    const int h = which & 1;
-    const int trow = which < 2 ? ((u >> 6) * 128 + h * 64 + (u & 63)) : ((u >> 5) * 64 + h * 32 + (u & 31));
-    int gr = r0 + trow;
-    gr = gr < rmax ? gr : rmax - 1;
-    glds16(G + (size_t)gr * ld + k0 + chunk * 8, unit + i * 1024);
-  }
-}
 
 __device__ __forceinline__ bf16x8 read_frag3(const char* unit, int ubase, int kk, int lane) {
   const int u = ubase + (lane & 15);
@@ -644,144 +474,6 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* unit, int ubase, int kk
   return *reinterpret_cast<const bf16x8*>(unit + u * 128 + ((c ^ (u & 7)) << 4));
 }
 
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                          int M, int N, int K, int lda, int ldb, int tiles_m,
-                                                          int tiles_n, Epi epi) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * UNIT3];   // [K-tile parity][A-mh0 | A-mh1 | B-nh0 | B-nh1]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int nwg = gridDim.x;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  constexpr int GROUP = 2;
-  const int per_group = GROUP * tiles_n;
-  const int grp = id / per_group;
-  const int first_m = grp * GROUP;
-  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (id % per_group) % gsz;
-  const int tn = (id % per_group) / gsz;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / BK3;
-  auto issue = [&](int t, int which) {
-    const int kt = t < nk ? t : nk - 1;
-    char* unit = smem + ((t & 1) * 4 + which) * UNIT3;
-    if (which < 2) stage_unit3(A, lda, m0, M, kt * BK3, which, unit, wave, lane);
-    else stage_unit3(B, ldb, n0, N, kt * BK3, which, unit, wave, lane);
-  };
-  issue(0, 0); issue(0, 2); issue(0, 3); issue(0, 1);
-  issue(1, 0); issue(1, 2); issue(1, 3);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wave >= 4) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
-#ifdef O2_STAMP
-  unsigned tL = 0, tBa = 0, tM = 0, tV = 0, tBb = 0, t0 = O2_T(), t1;
-  const unsigned tstart = t0;
-#endif
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-#define O2_MFMA_Q(MI, NJ, FB)                                                                              \
-  __builtin_amdgcn_s_setprio(1);                                                                           \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-    acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0); \
-  __builtin_amdgcn_s_setprio(0);
-  for (int t = 0; t < nk; ++t) {
-    const char* ub = smem + (t & 1) * 4 * UNIT3;
-    // ---- p0
-    issue(t + 1, 1);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = read_frag3(ub + 2 * UNIT3, wn * 32 + j * 16, kk, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag3(ub, wm * 64 + i * 16, kk, lane);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    O2_SEG(tL)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBa)
-    O2_MFMA_Q(0, 0, fb0)
-    O2_SEG(tM)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBb)
-    // ---- p1
-    issue(t + 2, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = read_frag3(ub + 3 * UNIT3, wn * 32 + j * 16, kk, lane);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    O2_SEG(tL)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBa)
-    O2_MFMA_Q(0, 2, fb1)
-    O2_SEG(tM)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBb)
-    // ---- p2
-    issue(t + 2, 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag3(ub + UNIT3, wm * 64 + i * 16, kk, lane);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    O2_SEG(tL)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBa)
-    O2_MFMA_Q(4, 2, fb1)
-    O2_SEG(tM)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBb)
-    // ---- p3
-    issue(t + 2, 3);
-    O2_SEG(tL)
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    O2_SEG(tV)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBa)
-    O2_MFMA_Q(4, 0, fb0)
-    O2_SEG(tM)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tBb)
-  }
-#undef O2_MFMA_Q
-  if (wave < 4) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dead-slot loads before LDS is released
-#ifdef O2_STAMP
-  if (blockIdx.x < 64 && (wave & 3) == 0 && lane == 0) {
-    unsigned* d = o2_dbg + (blockIdx.x * 2 + (wave >> 2)) * 8;
-    d[0] = tL; d[1] = tBa; d[2] = tM; d[3] = tV; d[4] = tBb; d[5] = O2_T() - tstart; d[6] = (unsigned)nk; d[7] = 1;
-  }
-#endif
-  epilogue256(epi, acc, m0, n0, wm, wn, lane);
-}
-
-// ==========================================================================================
-// The same 8-phase schedule for the forms with a K-STRIDED operand (weight gradients dW = dY^T.X: both operands;
-// input gradients dX = dY.W on the stored weight: B).  A K-strided operand is fetched as rows of k, so a unit must be
-// 128 CONTIGUOUS columns (whole 256-byte pieces per k row): unit h of an operand = tile rows / columns h*128 + [0, 128),
-// image [64 k][128 cols] with the 128-tile kernel's granule swizzle, fragments by ds_read_b64_tr_b16.  Wave (wm, wn)
-// therefore owns rows h*128 + wm*64 + [0, 64) and columns h*128 + wn*32 + [0, 32) of BOTH halves h (epilogue256<64, 128, 32,
-// 128>).  K-contiguous operands use the same row sets with the [128 rows][64 k] image of the NT kernel.
-// Schedule as above except that fragment reads stay IN FLIGHT across the barrier that ends L (their latency hides behind
-// the barrier's; the wait sits in front of the first MFMA): a unit may then only be re-filled TWO phases after its last
-// read (the other wave group retires its reads one barrier later), which the order
-//   p0: issue A-h1(t+1) | p1: issue B-h0(t+2) | p2: issue A-h0(t+2) | p3: issue B-h1(t+2)
-// satisfies for all but B-h0 (read p0, re-filled p1): p0 therefore issues its B reads first and retires them -- only
-// them -- with a counted lgkmcnt before its barrier.
-// ==========================================================================================
 template <bool KC>
 __device__ __forceinline__ void stage_unit4(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int h,
                                             char* unit, int wave, int lane) {
@@ -1080,9 +772,7 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (((a->a_kc || a->b_kc) && a->K % 8) || a->N % 8 || (!a->a_kc && a->M % 8) || a->lda % 8 || a->ldb % 8 ||
       a->ldc % 4)
     return O2_ERR_ARG;
-  if (a->tile_hint == 256 && a->K % BK2) return O2_ERR_ARG;
-  if (a->tile_hint == 257 && (a->K % BK3 || !a->a_kc || !a->b_kc)) return O2_ERR_ARG;
-  if (a->tile_hint == 258 && (a->K % BK3 || a->M < 8 || a->N < 8)) return O2_ERR_ARG;
+  if (a->tile_hint >= 256 && a->tile_hint <= 258 && a->K % BK3) return O2_ERR_ARG;   // the 8-phase kernel: whole 64-deep K-tiles
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
@@ -1114,7 +804,7 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
     if (a->K % BK3 || a->K < 2 * BK3 || a->M < 256 || a->N < 256) big = false;
     t256 += (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   }
-  if (args[0].tile_hint != 258 && t256 < 192) big = false;
+  if (args[0].tile_hint < 256 && t256 < 192) big = false;
   const int TB = big ? 256 : 128;
   int total = 0;
   for (int i = 0; i < n; ++i) {
@@ -1155,23 +845,20 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bf16_t* A = (const bf16_t*)a->A;
   const bf16_t* B = (const bf16_t*)a->B;
-  // tile choice: the 256^2 ring kernel (1 workgroup/CU) needs enough tiles to fill the chip; the 128^2 kernel
+  // tile choice: the 256^2 8-phase kernel (1 workgroup/CU) needs enough tiles to fill the chip; the 128^2 kernel
   // (2 workgroups/CU) takes small or ragged problems.  tile_hint forces one (tests / tuning).
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
-  if (tile != 128 && tile != 256 && tile != 257 && tile != 258) {
-    // measured on MI355X (tools/gemm_bench.py, interm_1b shapes, random data, profiles/r01_gemm_bench_shapes.txt):
-    // the staggered ring kernel wins for the K-contiguous (NT) form whenever it can fill the chip; the 128^2
-    // kernel (2 workgroups/CU) wins for both K-strided forms and for small / ragged problems.
+  if (tile == 257 || tile == 258) tile = 256;       // hints of the round-2 A/B tools: the same kernel
+  if (tile != 128 && tile != 256) {
+    // measured on MI355X (tools/gemm_p8_ab.py, tools/gemm_t8_ab.py; profiles/r02_gemm_*): the 8-phase 256-tile kernel wins
+    // in every operand form whenever its tiles fill the chip; the 128^2 kernel (2 workgroups/CU, ragged K) takes small
+    // or ragged problems
     const long rounds = (t256 + 255) / 256;
     const double util = (double)t256 / (double)(rounds * 256);
-    const bool nt = a->a_kc && a->b_kc;
-    tile = (nt && a->K % BK2 == 0 && a->M >= 256 && a->N >= 256 && t256 >= 192 && util >= 0.70) ? 256 : 128;
-    // 64-deep K-tiles (8-phase kernel): bit-identical results, 8-15 % faster than the 32-deep ring on the interm_1b
-    // shapes (tools/gemm_p8_ab.py, profiles/r02_gemm_p8_ab.txt); needs K % 64 == 0 and at least two K-tiles
-    if (tile == 256 && a->K % BK3 == 0 && a->K >= 2 * BK3) tile = 257;
+    tile = (a->K % BK3 == 0 && a->K >= 2 * BK3 && a->M >= 256 && a->N >= 256 && t256 >= 192 && util >= 0.70) ? 256 : 128;
   }
-  if (tile == 258) {
+  if (tile == 256) {
     const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
     dim3 grid(tiles_m * tiles_n), block(512);
     if (a->a_kc && a->b_kc)
@@ -1185,31 +872,6 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
                          tiles_m, tiles_n, e);
     else
       hipLaunchKernelGGL((gemm256t_kernel<false, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
-                         tiles_m, tiles_n, e);
-    O2_CHECK_LAUNCH();
-    return O2_OK;
-  }
-  if (tile == 257) {
-    const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
-    hipLaunchKernelGGL(gemm256p_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
-                       tiles_m, tiles_n, e);
-    O2_CHECK_LAUNCH();
-    return O2_OK;
-  }
-  if (tile == 256) {
-    const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
-    dim3 grid(tiles_m * tiles_n), block(512);
-    if (a->a_kc && a->b_kc)
-      hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
-                         tiles_m, tiles_n, e);
-    else if (a->a_kc && !a->b_kc)
-      hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
-                         tiles_m, tiles_n, e);
-    else if (!a->a_kc && a->b_kc)
-      hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
-                         tiles_m, tiles_n, e);
-    else
-      hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,
                          tiles_m, tiles_n, e);
     O2_CHECK_LAUNCH();
     return O2_OK;

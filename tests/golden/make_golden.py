@@ -249,6 +249,13 @@ def main():
                             default_vars=CONST + ["2m_temperature", "10m_u_component_of_wind",
                                                   "total_precipitation_24hr"],
                             grid=(8, 16), run_grid=(16, 32), D=32, depth=1, heads=2, dd=1),
+        # the same re-gridded case at a head dim the HIP attention supports (64): GPU parity of the bicubic branch
+        "v6c2_regrid_hd64": dict(in_vars=["2m_temperature", "lattitude", "orography", "landcover", "land_sea_mask",
+                                          "total_precipitation_24hr"],
+                                 out_vars=["total_precipitation_24hr", "2m_temperature"],
+                                 default_vars=CONST + ["2m_temperature", "10m_u_component_of_wind",
+                                                       "total_precipitation_24hr"],
+                                 grid=(8, 16), run_grid=(16, 32), D=128, depth=1, heads=2, dd=1),
     }
     for tag, c in cases.items():
         torch.manual_seed(0)

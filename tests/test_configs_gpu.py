@@ -1,0 +1,141 @@
+"""Whole-model GPU tests of the BASELINE configurations that round 1 only covered kernel by kernel:
+configs[1] interm_117m (D1024 / 16 heads of 64 / depth 8, 23 -> 3 variables, 32x64 -> 128x256): forward + loss + backward
+against the CPU oracle; configs[3] interm_10b (D8192 / 32 heads of 256 / depth 11, 9.47 B parameters): one training step
+with activation recompute at batch 1 -- finite loss, recompute == saved-activation gradients bit for bit on a Block,
+batch independence.  Reference: configs/interm_{117m,10b}.yaml:27-45, res_slimvit.py:312-338."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+ERA5_VARS = CONST + [
+    "2m_temperature", "2m_temperature_max", "2m_temperature_min", "temperature_200", "temperature_500",
+    "temperature_850", "10m_u_component_of_wind", "u_component_of_wind_200", "u_component_of_wind_500",
+    "u_component_of_wind_850", "10m_v_component_of_wind", "v_component_of_wind_200", "v_component_of_wind_500",
+    "v_component_of_wind_850", "specific_humidity_200", "specific_humidity_500", "specific_humidity_850",
+    "total_precipitation_24hr", "volumetric_soil_water_layer_1"]
+OUT_VARS = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+VW = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0}
+
+
+def nerr(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def test_interm_117m_whole_model_forward_backward_vs_oracle():
+    """BASELINE configs[1] at its real architecture and grid (2 of the 8 samples of the YAML batch: the oracle runs them
+    on the CPU in seconds): prediction <= 2e-2, loss <= 1e-2, every parameter gradient <= 5e-2 (normalised max) or <= 2e-2
+    relative L2 -- the tolerances of the reference-golden whole-model test"""
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.trainer import training_step
+    from oracle.harness import build_pair
+    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=1024, depth=8, heads=16, dd=4, grid=(32, 64), B=2, seed=11,
+                                                            out_vars=OUT_VARS, in_vars=ERA5_VARS)
+    n = sum(p.numel() for p in model.parameters())
+    assert 1.09e8 < n < 1.12e8 and len(in_vars) == 23            # 110 035 331 in the reference
+    dev = torch.device("cuda")
+    model = model.to(dev).eval()
+    loss = training_step((x, y, in_vars, out_vars), 0, model, dev, VW, Bayesian_TV(aggregate_only=True))
+    loss.backward()
+    with torch.no_grad():
+        pred = model(x.to(dev), in_vars, out_vars)
+    torch.cuda.synchronize()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    pref = O.forward(sdo, cfg, x, in_vars, out_vars)
+    assert tuple(pred.shape) == (2, 3, 128, 256) and nerr(pred, pref) < 2e-2
+    ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", VW)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 1e-2
+    worst, l2 = {}, {}
+    for name, p in model.named_parameters():
+        g = sdo[name].grad
+        if g is None:
+            continue
+        assert p.grad is not None, name
+        worst[name], l2[name] = nerr(p.grad, g), rel_l2(p.grad, g)
+    print(sorted(((round(e, 4), round(l2[k], 4), k) for k, e in worst.items()), reverse=True)[:10])
+    bad = {k: (e, l2[k]) for k, e in worst.items() if e > 5e-2 and l2[k] > 2e-2}
+    assert len(worst) > 120 and not bad, bad
+    assert max(l2.values()) < 6e-2, max(l2.items(), key=lambda kv: kv[1])
+
+
+def test_interm_10b_training_step_with_recompute():
+    """BASELINE configs[3]: interm_10b (9.47 B parameters at the 128x256 grid) on ONE GPU, batch 1, every Block replayed
+    in backward, bf16 compute / fp32 master, dropout on.  Size-independent properties: finite descending-capable step
+    (finite loss, finite non-zero gradients in every unit, parameters move), recompute vs saved activations bit-identical
+    on one Block's gradients, eval predictions independent of the batch neighbour."""
+    import climate_learn as cl
+    from climate_learn import _ops
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub import Res_Slim_ViT
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    dev = torch.device("cuda")
+    h, w = 128, 256
+    with torch.device(dev):
+        model = Res_Slim_ViT(ERA5_VARS, (h, w), 23, 3, 1, superres_mag=4, cnn_ratio=4, patch_size=2, drop_path=0.1,
+                             drop_rate=0.1, learn_pos_emb=True, embed_dim=8192, depth=11, decoder_depth=4, num_heads=32,
+                             mlp_ratio=4, FusedAttn_option=cl.FusedAttn.HIP)
+    model.data_config(156.0, (h, w), 23, 3)
+    n = sum(p.numel() for p in model.parameters())
+    assert 9.4e9 < n < 9.55e9
+    for blk in model.blocks:
+        blk.recompute = True
+    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential))
+    opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 23, h, w, generator=g)
+    y = torch.randn(1, 3, 721, 1440, generator=g)
+    y[:, 0] = torch.log1p(torch.relu(y[:, 0]))
+    batch = (x.to(dev), y.to(dev), ERA5_VARS, OUT_VARS)
+    loss_fn = Bayesian_TV(aggregate_only=True)
+    eng.train()
+    cl.manual_seed(0)
+    w0 = model.blocks[5].mlp.fc1.weight.detach()[:4, :64].clone()
+    mark = _ops.seeds.mark()
+    loss = training_step(batch, 0, eng, dev, VW, loss_fn)
+    opt.zero_grad()
+    scaler.scale(loss).backward()
+    eng.finish_grad_sync()
+    assert torch.isfinite(loss) and 0.0 < float(loss) < 1e3
+    for bk in eng.buckets:                                  # every unit got finite, non-zero gradients
+        for v in bk.grad_views:
+            assert torch.isfinite(v.float()).all() and float(v.float().abs().sum()) > 0, bk.name
+    g_rec = model.blocks[10].attn.qkv.weight._o2g.clone()
+    g_rec2 = model.blocks[0].mlp.fc2.weight._o2g.clone()
+    # the same step with saved activations on the first and last Block: bit-identical gradients there
+    model.blocks[10].recompute = False
+    model.blocks[0].recompute = False
+    _ops.seeds.reset(mark)
+    loss2 = training_step(batch, 0, eng, dev, VW, loss_fn)
+    opt.zero_grad()
+    scaler.scale(loss2).backward()
+    eng.finish_grad_sync()
+    assert float(loss2) == float(loss)
+    assert torch.equal(model.blocks[10].attn.qkv.weight._o2g, g_rec)
+    assert torch.equal(model.blocks[0].mlp.fc2.weight._o2g, g_rec2)
+    scaler.step(opt)
+    assert scaler.update() is False                         # no overflow at the initial loss scale
+    torch.cuda.synchronize()
+    assert not torch.equal(model.blocks[5].mlp.fc1.weight.detach()[:4, :64], w0)      # the optimizer moved the weights
+    del g_rec, g_rec2
+    # batch independence of the eval forward at the real size
+    eng.eval()
+    opt.zero_grad()
+    x2 = torch.randn(2, 23, h, w, generator=g).to(dev)
+    with torch.no_grad():
+        y2 = eng(x2, ERA5_VARS, OUT_VARS)
+        y1 = eng(x2[1:2].contiguous(), ERA5_VARS, OUT_VARS)
+    assert y2.shape == (2, 3, 512, 1024) and torch.isfinite(y2).all() and torch.equal(y2[1:2], y1)

@@ -101,6 +101,12 @@ CASES = {
                         default_vars=CONST + ["2m_temperature", "10m_u_component_of_wind",
                                               "total_precipitation_24hr"],
                         grid=(16, 32), D=32, depth=1, heads=2, dd=1),
+    "v6c2_regrid_hd64": dict(in_vars=["2m_temperature", "lattitude", "orography", "landcover", "land_sea_mask",
+                                      "total_precipitation_24hr"],
+                             out_vars=["total_precipitation_24hr", "2m_temperature"],
+                             default_vars=CONST + ["2m_temperature", "10m_u_component_of_wind",
+                                                   "total_precipitation_24hr"],
+                             grid=(16, 32), D=128, depth=1, heads=2, dd=1),
 }
 VW = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0,
       "2m_temperature": 10.0}
