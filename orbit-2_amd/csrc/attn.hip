@@ -69,7 +69,7 @@ __device__ __forceinline__ void stage_keyhash(uint32_t* skh, uint64_t seed, int 
   if (tid < 16) skh[(tid & 1) * 8 + (tid >> 1)] = o2_attn_keyhash(seed, (uint32_t)(tile * 16 + tid));
 }
 
-// Workgroup -> (128-row tile, head, batch).  The grid is launched one-dimensional; hardware deals consecutive
+// Workgroup -> (row tile of NW*32 rows, head, batch).  The grid is launched one-dimensional; hardware deals consecutive
 // workgroups round-robin to the 8 XCDs, so the id is first remapped (bijectively, any grid size) to give every XCD a
 // CONTIGUOUS range of tile ids: the ~64 workgroups an XCD runs at a time are then consecutive tiles of one or two
 // (batch, head) pairs and share that pair's K/V (or Q/dO) through the XCD's L2, instead of every XCD streaming the
@@ -87,8 +87,12 @@ __device__ __forceinline__ void attn_tile_coords(int nq, int H, int& qt, int& he
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int D, bool DROP, bool RAGGED>
-__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// NW = waves per workgroup (32 query rows each).  8 waves (256-row tiles, one workgroup per CU) share every K/V tile:
+// half the LDS-DMA pieces per wave and per MFMA of the 4-wave / two-workgroups-per-CU form (the stamps of that form,
+// profiles/r02_attn_fwd_stamps_4wave.txt, show 8 pieces per wave and tile costing 700-970 of ~3200-5100 cycles: the CU's
+// LDS write path is busy ~11 cycles per 1-KiB piece and all 8 resident waves queue on it).
+template <int D, bool DROP, bool RAGGED, int NW>
+__global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
                                                           unsigned thr, float dscale, uint64_t seed_arg) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;  // MFMA half
   int tile_i, head, b;
-  attn_tile_coords((L + 127) / 128, H, tile_i, head, b);
-  const int q0 = tile_i * 128 + wave * 32;
+  attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
+  const int q0 = tile_i * (NW * 32) + wave * 32;
   const size_t tstride = (size_t)3 * H * D;  // token stride in qkv
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
   const uint32_t rowhash = DROP ? o2_attn_rowhash(seed, (uint64_t)(b * H + head) * L + (uint64_t)qrow) : 0u;
 
   const int nt = (L + 63) / 64;
-  stage64<D, RAGGED>(kbase, tstride, smem, wave, lane, L);
-  stage64<D, RAGGED>(vbase, tstride, smem + C::TILE, wave, lane, L);
+  stage64<D, RAGGED, NW>(kbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED, NW>(vbase, tstride, smem + C::TILE, wave, lane, L);
   if (DROP) stage_keyhash(skh[0], seed, 0, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const
     const char* sv = sk + C::TILE;
     if (t + 1 < nt) {
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D, RAGGED>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
-      stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
       if (DROP) stage_keyhash(skh[cur ^ 1], seed, t + 1, tid);
     }
     O2_SEG(tS)
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =============================================================================================
 // backward, dQ: same geometry as the forward (query on the lane)
 // =============================================================================================
-template <int D, bool DROP, bool RAGGED>
-__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+template <int D, bool DROP, bool RAGGED, int NW>
+__global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                              const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;
   int tile_i, head, b;
-  attn_tile_coords((L + 127) / 128, H, tile_i, head, b);
-  const int q0 = tile_i * 128 + wave * 32;
+  attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
+  const int q0 = tile_i * (NW * 32) + wave * 32;
   const size_t tstride = (size_t)3 * H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -322,8 +326,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
   const int nt = (L + 63) / 64;
-  stage64<D, RAGGED>(kbase, tstride, smem, wave, lane, L);
-  stage64<D, RAGGED>(vbase, tstride, smem + C::TILE, wave, lane, L);
+  stage64<D, RAGGED, NW>(kbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED, NW>(vbase, tstride, smem + C::TILE, wave, lane, L);
   if (DROP) stage_keyhash(skh[0], seed, 0, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -333,8 +337,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
     const char* sv = sk + C::TILE;
     if (t + 1 < nt) {
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D, RAGGED>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
-      stage64<D, RAGGED>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
       if (DROP) stage_keyhash(skh[cur ^ 1], seed, t + 1, tid);
     }
 #pragma unroll
@@ -383,13 +387,13 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dq_kernel(co
 }
 
 // =============================================================================================
-// backward, dK/dV: key on the lane; the workgroup owns 128 keys (32 per wave) and sweeps all queries
+// backward, dK/dV: key on the lane; the workgroup owns NW*32 keys (32 per wave) and sweeps all queries
 // =============================================================================================
 // WHICH: 0 = dK and dV in one pass (d = 64: fits 2 waves/SIMD);  1 = dK only;  2 = dV only.
 // At d = 128 the fused form needs 236 VGPR + 160 AGPR (1 wave/SIMD, measured 576 TFLOP/s executed); split in two
 // passes (5 MFMA products instead of 4) each pass fits 2 waves/SIMD.
-template <int D, bool DROP, int WHICH, bool RAGGED>
-__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
+template <int D, bool DROP, int WHICH, bool RAGGED, int NW>
+__global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
@@ -403,8 +407,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hq = lane >> 5;
   int tile_i, head, b;
-  attn_tile_coords((L + 127) / 128, H, tile_i, head, b);
-  const int k0 = tile_i * 128 + wave * 32;
+  attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
+  const int k0 = tile_i * (NW * 32) + wave * 32;
   const size_t tstride = (size_t)3 * H * D;
   const size_t ostride = (size_t)H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
     }
   };
-  stage64<D, RAGGED>(qbase, tstride, smem, wave, lane, L);
-  stage64<D, RAGGED>(dobase, ostride, smem + C::TILE, wave, lane, L);
+  stage64<D, RAGGED, NW>(qbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED, NW>(dobase, ostride, smem + C::TILE, wave, lane, L);
   stage_stats(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -462,8 +466,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kernel(c
     const char* sdo = sq + C::TILE;
     if (t + 1 < nt) {
       char* nq = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D, RAGGED>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane, L - (t + 1) * 64);
-      stage64<D, RAGGED>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane, L - (t + 1) * 64);
       stage_stats(t + 1, cur ^ 1);
     }
     const float* s_lse = sstat + (cur * 3 + 0) * 64;
@@ -595,6 +599,28 @@ static int attn_check(const void* a, const void* b, int B, int L, int H, int d, 
   return O2_OK;
 }
 
+// waves per workgroup: 8 (256-row tiles, K/V or Q/dO tiles shared by twice the waves) whenever the sequence has at least
+// one such tile and the kernel fits two waves per SIMD (d = 64, 128); $ORBIT2_ATTN_WAVES=4 keeps the round-1 geometry (A/B)
+static int attn_waves(int L, int d) {
+  if (d == 256 || L < 256) return 4;
+  const char* e = getenv("ORBIT2_ATTN_WAVES");
+  return (e && e[0] == '4') ? 4 : 8;
+}
+
+template <int DV, bool DR, bool RG, int NW>
+static void launch_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, float sc_log2, unsigned thr, float dscale,
+                       uint64_t seed, hipStream_t s) {
+  dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
+  hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, RG, NW>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
+                     thr, dscale, seed);
+}
+template <int DV, bool DR, int NW>
+static void launch_fwd_r(bool ragged, const void* qkv, void* out, float* lse, int B, int L, int H, float sc_log2, unsigned thr,
+                         float dscale, uint64_t seed, hipStream_t s) {
+  if (ragged) launch_fwd<DV, DR, true, NW>(qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);
+  else launch_fwd<DV, DR, false, NW>(qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);
+}
+
 extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
                                uint64_t seed, void* stream) {
   int rc = attn_check(qkv, out, B, L, H, d, drop_p);
@@ -603,24 +629,48 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
   const float sc_log2 = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
-  dim3 grid(((L + 127) / 128) * H * B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const bool ragged = (L % 128) != 0;
-#define O2_FWD(DV, DR)                                                                                              \
-  do {                                                                                                              \
-    if (ragged)                                                                                                     \
-      hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, true>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out,    \
-                         lse, L, H, sc_log2, thr, dscale, seed);                                                    \
-    else                                                                                                            \
-      hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, false>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out,   \
-                         lse, L, H, sc_log2, thr, dscale, seed);                                                    \
+  const int nw = attn_waves(L, d);
+  const bool ragged = (L % (nw * 32)) != 0;
+#define O2_FWD(DV, NWV)                                                                              \
+  do {                                                                                               \
+    if (thr) launch_fwd_r<DV, true, NWV>(ragged, qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);  \
+    else launch_fwd_r<DV, false, NWV>(ragged, qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);     \
   } while (0)
-  if (d == 256) { if (thr) O2_FWD(256, true); else O2_FWD(256, false); }
-  else if (d == 128) { if (thr) O2_FWD(128, true); else O2_FWD(128, false); }
-  else { if (thr) O2_FWD(64, true); else O2_FWD(64, false); }
+  if (d == 256) O2_FWD(256, 4);
+  else if (d == 128) { if (nw == 8) O2_FWD(128, 8); else O2_FWD(128, 4); }
+  else { if (nw == 8) O2_FWD(64, 8); else O2_FWD(64, 4); }
 #undef O2_FWD
   O2_CHECK_LAUNCH();
   return O2_OK;
+}
+
+template <int DV, bool DR, bool RG, int NW>
+static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta, bf16_t* dq_, int B, int L,
+                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s) {
+  dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
+                     seed);
+  if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
+                       dscale, seed);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 1, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
+                       dscale, seed);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 2, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
+                       dscale, seed);
+  }
+}
+template <int DV, int NW>
+static void launch_bwd_r(bool drop, bool ragged, const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta,
+                         bf16_t* dq_, int B, int L, int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s) {
+  if (drop) {
+    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+  } else {
+    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+  }
 }
 
 extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
@@ -636,37 +686,19 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, s,
                      (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
   O2_CHECK_LAUNCH();
-  dim3 grid(((L + 127) / 128) * H * B), block(256);
   const bf16_t* q_ = (const bf16_t*)qkv;
   const bf16_t* do_ = (const bf16_t*)dout;
   bf16_t* dq_ = (bf16_t*)dqkv;
-  const bool ragged = (L % 128) != 0;
-#define O2_DQ(DV, DR)                                                                                               \
-  do {                                                                                                              \
-    if (ragged) hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, true>), grid, block, 0, s, q_, do_, lse, delta, dq_, \
-                                   L, H, scale, thr, dscale, seed);                                                 \
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, false>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, \
-                            scale, thr, dscale, seed);                                                              \
-  } while (0)
-#define O2_DKV(DV, DR, W)                                                                                           \
-  do {                                                                                                              \
-    if (ragged) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W, true>), grid, block, 0, s, q_, do_, lse, delta,  \
-                                   dq_, L, H, scale, thr, dscale, seed);                                            \
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, W, false>), grid, block, 0, s, q_, do_, lse, delta, dq_,   \
-                            L, H, scale, thr, dscale, seed);                                                        \
-  } while (0)
-  if (d == 256) {
-    if (thr) { O2_DQ(256, true); O2_DKV(256, true, 1); O2_DKV(256, true, 2); }
-    else { O2_DQ(256, false); O2_DKV(256, false, 1); O2_DKV(256, false, 2); }
-  } else if (d == 128) {
-    if (thr) { O2_DQ(128, true); O2_DKV(128, true, 1); O2_DKV(128, true, 2); }
-    else { O2_DQ(128, false); O2_DKV(128, false, 1); O2_DKV(128, false, 2); }
+  const int nw = attn_waves(L, d);
+  const bool ragged = (L % (nw * 32)) != 0;
+  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+  else if (d == 128) {
+    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
   } else {
-    if (thr) { O2_DQ(64, true); O2_DKV(64, true, 0); }
-    else { O2_DQ(64, false); O2_DKV(64, false, 0); }
+    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
   }
-#undef O2_DQ
-#undef O2_DKV
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

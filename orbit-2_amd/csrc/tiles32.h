@@ -26,14 +26,15 @@ __device__ __forceinline__ int swz(int row) {
 
 // stage a [64 rows][D] tile; rows are tokens tok0..tok0+63 of one head: src(row) = base + row*stride
 // (rows >= nvalid are read from row nvalid-1: ragged sequence lengths never touch memory outside the tensor)
-template <int D, bool RAGGED>
+template <int D, bool RAGGED, int NW = 4>     // NW: waves of the workgroup sharing the staging (4 or 8)
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t stride, char* tile, int wave,
                                         int lane, int nvalid) {
   using C = Cfg<D>;
-  constexpr int NI = C::TILE / 1024;  // instructions per tile (16 or 8)
+  constexpr int NI = C::TILE / 1024;  // instructions per tile (8, 16 or 32)
+  static_assert(NI % NW == 0, "tile pieces must divide over the waves");
 #pragma unroll
-  for (int t = 0; t < NI / 4; ++t) {
-    const int i = wave * (NI / 4) + t;
+  for (int t = 0; t < NI / NW; ++t) {
+    const int i = wave * (NI / NW) + t;
     const int row = i * C::RPI + lane / C::CPR;
     const int cp = lane % C::CPR;
     const int c = cp ^ swz<D>(row);
