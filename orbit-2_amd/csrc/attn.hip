@@ -87,6 +87,13 @@ __device__ __forceinline__ void attn_tile_coords(int nq, int H, int& qt, int& he
 // =============================================================================================
 // forward
 // =============================================================================================
+// Measured and not kept (round 2, profiles/r02_attn_fwd_pingpong_*.txt): a software-pipelined ping-pong form of this loop
+// (fragments preloaded into registers, pure 16-MFMA segments, waves 4-7 one segment behind waves 0-3, inline-asm LDS-DMA
+// rings) is bit-identical and its MFMA segments run at 500-550 cycles per 16 MFMAs, but a wave's vector-ALU + LDS-issue
+// + staging work per 64-key tile (~1650 cycles, ~2300 with dropout) is 1.6-2.2x its 1024 MFMA cycles: strict alternation
+// costs 2 x that, the free-running loop below already sits near (vector + MFMA) per wave with the SIMD's two waves
+// overlapping each other: -4 ... -7 % at d = 128.  The lever left is the vector instruction count per score element.
+//
 // NW = waves per workgroup (32 query rows each).  8 waves (256-row tiles, one workgroup per CU) share every K/V tile:
 // half the LDS-DMA pieces per wave and per MFMA of the 4-wave / two-workgroups-per-CU form (the stamps of that form,
 // profiles/r02_attn_fwd_stamps_4wave.txt, show 8 pieces per wave and tile costing 700-970 of ~3200-5100 cycles: the CU's
@@ -231,259 +238,6 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
 #endif
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
-  if (!q_ok) return;
-  if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
-  bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
-#pragma unroll
-  for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int dd = db * 32 + 8 * g4 + 4 * hq;
-      u32x2 w;
-      w[0] = pack_bf2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
-      w[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-      *reinterpret_cast<u32x2*>(orow + dd) = w;
-    }
-}
-
-// =============================================================================================
-// forward, 8 waves, software-pipelined and ping-ponged
-// =============================================================================================
-// The stamps of the plain loop above (profiles/r02_attn_fwd_stamps_4wave.txt) show a wave spending 3200-5100 cycles per
-// 64-key tile for 1024 cycles of its own MFMAs: the two waves of a SIMD run the same program in lockstep (one barrier per
-// tile), so they want the matrix pipe at the same time and the vector ALU at the same time.  Here the tile loop is cut into
-//   X(j): S(j+1) = K(j+1) Q^T  and  O += V(j)^T P(j)     32 MFMAs + their fragment reads, nothing else
-//   Y(j): softmax / dropout of S(j) -> P(j), LDS-DMA issue of K(j+3), V(j+2)      vector ALU + staging, no MFMA
-// separated by s_barrier, and waves 4-7 run ONE segment behind waves 0-3: on every SIMD one wave is in X while its
-// partner is in Y.  (P(j) is consumed by the X that follows its Y, S(j+1) by the Y that follows its X; an O rescale in Y(j+1)
-// comes after the PV of tile j has been issued, so O, l and P always share one reference maximum.)
-// LDS: K and V rings of 4 tiles each (128 KiB at d = 128).  K(j+3) / V(j+2) issued in Y(j) replace K(j-1) / V(j-2), last read
-// two or more segments earlier by either wave group.  Every X ends with a counted vmcnt that leaves only the youngest Y's
-// pieces in flight: a tile's pieces have landed for BOTH groups one barrier before its first reader.
-template <int D, bool DROP, bool RAGGED>
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                             float* __restrict__ lse, int L, int H, float sc_log2,
-                                                             unsigned thr, float dscale, uint64_t seed_arg) {
-  const uint64_t seed = seed_arg ^ o2_seed_salt;
-  using C = Cfg<D>;
-  constexpr int NW = 8;
-  constexpr int PPT = C::TILE / 1024 / NW;      // LDS-DMA pieces per wave and tile (2 at d = 128, 1 at d = 64)
-  // ONE __shared__ object (with a second one beside the LDS-DMA target hipcc puts a vmcnt(0) in front of the first ds_read
-  // of every segment, draining the whole prefetch ring): K ring [4] | V ring [4] | key-group hashes of 4 tiles (dropout)
-  __shared__ __attribute__((aligned(16))) char smem[8 * C::TILE + 4 * 16 * 4];
-  uint32_t (*skh)[16] = reinterpret_cast<uint32_t (*)[16]>(smem + 8 * C::TILE);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hq = lane >> 5;
-  int tile_i, head, b;
-  attn_tile_coords((L + 255) / 256, H, tile_i, head, b);
-  const int q0 = tile_i * 256 + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;
-  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
-  const bf16_t* kbase = qbase + (size_t)H * D;
-  const bf16_t* vbase = qbase + (size_t)2 * H * D;
-  const int qrow_raw = q0 + (lane & 31);
-  const bool q_ok = !RAGGED || qrow_raw < L;
-  const int qrow = q_ok ? qrow_raw : L - 1;
-
-  bf16x8 qf[C::NDS];
-#pragma unroll
-  for (int ds = 0; ds < C::NDS; ++ds)
-    qf[ds] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq);
-  // retire these ordinary loads NOW: a register load still pending when the LDS-DMA ring starts makes hipcc put vmcnt(0) in
-  // front of the Q fragments' first use in every loop path, which drains the ring's prefetch each time
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-
-  f32x16 o[C::NDB];
-#pragma unroll
-  for (int i = 0; i < C::NDB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const uint32_t rowhash = DROP ? o2_attn_rowhash(seed, (uint64_t)(b * H + head) * L + (uint64_t)qrow) : 0u;
-
-  const int nt = (L + 63) / 64;
-  char* kring = smem;
-  char* vring = smem + 4 * C::TILE;
-  const uint32_t kring_lds = lds_addr(kring), vring_lds = lds_addr(vring);
-  auto issue_k = [&](int t) {
-    const int tc = t < nt ? t : nt - 1;       // tiles past the end: re-load the last one into a slot nobody reads again
-    stage64_asm<D, RAGGED, NW>(kbase + (size_t)tc * 64 * tstride, tstride, kring_lds + (t & 3) * C::TILE, wave, lane, L - tc * 64);
-  };
-  auto issue_v = [&](int t) {
-    const int tc = t < nt ? t : nt - 1;
-    stage64_asm<D, RAGGED, NW>(vbase + (size_t)tc * 64 * tstride, tstride, vring_lds + (t & 3) * C::TILE, wave, lane, L - tc * 64);
-  };
-  issue_k(0); issue_k(1); issue_v(0); issue_k(2); issue_v(1);
-  if (DROP) {                                        // tables of tiles 0 and 1 (Y(t) writes tile t+2's)
-    stage_keyhash(skh[0], seed, 0, tid);
-    if (tid >= 64) stage_keyhash(skh[1], seed, 1, tid - 64);
-  }
-  if (PPT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wave >= 4) __builtin_amdgcn_s_barrier();     // waves 4-7 run one segment behind
-
-  f32x16 s[2];
-  bf16x8 pf[2][2];                                  // P(j) as the PV operand fragments [key block][16-key step]
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-  // Lane parts of the fragment addresses, computed ONCE (left to itself hipcc hoists one address register per unrolled
-  // read out of the loop -- ~50 of them -- and spills; the reloads then sit, each behind a vmcnt(0), inside the MFMA
-  // segment).  A read's address = slot base (scalar) + lane part + constant (16-row blocks do not change the swizzle).
-  uint32_t koff[C::NDS], voff[C::NDB][2];
-  {
-    const int r = lane & 31;
-#pragma unroll
-    for (int ds = 0; ds < C::NDS; ++ds) koff[ds] = (uint32_t)(r * C::RB + (((ds * 2 + hq) ^ swz<D>(r)) << 4));
-    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-      for (int k8 = 0; k8 < 2; ++k8) {
-        const int row = 4 * hq + q + 8 * k8;
-        const int c = db * 4 + 2 * (g & 1) + (pq >> 1);
-        voff[db][k8] = (uint32_t)(row * C::RB + ((c ^ swz<D>(row)) << 4) + 8 * (pq & 1));
-      }
-  }
-  auto kfrag = [&](const char* sk_, int kb, int ds) {
-    return *reinterpret_cast<const bf16x8*>(sk_ + kb * 32 * C::RB + koff[ds]);
-  };
-  auto vfrag = [&](const char* sv_, int rbase, int db) {
-    const bf16x4 lo = lds_tr4(sv_ + rbase * C::RB + voff[db][0]), hi = lds_tr4(sv_ + rbase * C::RB + voff[db][1]);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-#ifdef O2_STAMP
-  unsigned tX = 0, tW = 0, tB1 = 0, tY = 0, tB2 = 0, t0_ = O2_T(), t1_;
-  const unsigned tstart_ = t0_;
-#endif
-  for (int j = -1; j < nt; ++j) {
-    // ------------------------------------------------------------------ X(j): S(j+1) and O += V(j)^T P(j)
-    const bool do_qk = j + 1 < nt, do_pv = j >= 0;
-    const char* sk = kring + ((j + 1) & 3) * C::TILE;
-    const char* sv = vring + (j & 3) * C::TILE;
-    __builtin_amdgcn_s_setprio(1);
-    if (do_qk && do_pv) {
-      // Both chains, in NG groups of 4 QK^T + 4 PV MFMAs.  The fragments of group g+1 are read while group g's MFMAs issue
-      // (two fragment sets, fenced so the compiler neither hoists every read to the top -- 128 fragment registers --
-      // nor waits for each group's reads right before its MFMAs).
-      constexpr int NG = C::NDS / 2;               // 4 at d = 128, 2 at d = 64
-      bf16x8 kfr[2][4], vfr[2][4];
-      auto load_group = [&](int g, bf16x8 (&kf_)[4], bf16x8 (&vf_)[4]) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ds = 2 * g + (u >> 1), kb = u & 1;
-          kf_[u] = kfrag(sk, kb, ds);
-          const int idx = 4 * g + u;
-          const int pkb = idx / (2 * C::NDB), pss = (idx / C::NDB) & 1, pdb = idx % C::NDB;
-          vf_[u] = vfrag(sv, pkb * 32 + pss * 16, pdb);
-        }
-      };
-      load_group(0, kfr[0], vfr[0]);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) load_group(g + 1, kfr[(g + 1) & 1], vfr[(g + 1) & 1]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ds = 2 * g + (u >> 1), kb = u & 1;
-          s[kb] = MFMA32(kfr[g & 1][u], qf[ds], s[kb]);
-          const int idx = 4 * g + u;
-          const int pkb = idx / (2 * C::NDB), pss = (idx / C::NDB) & 1, pdb = idx % C::NDB;
-          o[pdb] = MFMA32(vfr[g & 1][u], pf[pkb][pss], o[pdb]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else if (do_qk) {
-#pragma unroll
-      for (int ds = 0; ds < C::NDS; ++ds)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-          s[kb] = MFMA32(kfrag(sk, kb, ds), qf[ds], s[kb]);
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int db = 0; db < C::NDB; ++db)
-            o[db] = MFMA32(vfrag(sv, kb * 32 + ss * 16, db), pf[kb][ss], o[db]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    O2_SEG(tX)
-    if (PPT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    O2_SEG(tW)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tB1)
-    // ------------------------------------------------------------------ Y(j+1): softmax of S(j+1), staging
-    const int t = j + 1;
-    issue_k(t + 3);
-    issue_v(t + 2);
-    if (DROP && tid < 16) stage_keyhash(skh[(t + 2) & 3], seed, t + 2, tid);
-    if (do_qk) {
-      if (RAGGED && t == nt - 1 && (L & 63)) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) s[kb][r] = -1e30f;
-      }
-      float mx = -1e30f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      constexpr float RESCALE_THR = 5.0f;
-      const float mt = mx * sc_log2;
-      float alpha = 1.0f;
-      if (__any(mt > m_run + RESCALE_THR)) {
-        const float m_new = fmaxf(m_run, mt);
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < C::NDB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-      }
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[kb][r] * sc_log2 - m_run);
-          s[kb][r] = p;
-          psum += p;
-        }
-      l_run = l_run * alpha + psum;
-      if (DROP) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-          drop_keys_in_regs(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[t & 3][hq * 8 + kb * 4]), thr);
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) pf[kb][ss] = pack_frag(s[kb], ss);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)               // the next X accumulates S(j+2) from zero (cleared here, off the MFMA segment)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-    }
-    O2_SEG(tY)
-    __builtin_amdgcn_s_barrier();
-    O2_SEG(tB2)
-  }
-#ifdef O2_STAMP
-  if (blockIdx.x < 32 && (wave & 3) == 0 && lane == 0) {
-    unsigned* dd_ = o2_dbg_attn + (blockIdx.x * 2 + (wave >> 2)) * 8;
-    dd_[0] = tX; dd_[1] = tW; dd_[2] = tB1; dd_[3] = tY; dd_[4] = tB2; dd_[5] = 0; dd_[6] = O2_T() - tstart_; dd_[7] = (unsigned)nt;
-  }
-#endif
-  if (wave < 4) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dead-slot loads before LDS is released
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = (DROP ? dscale : 1.0f) / l_tot;
   if (!q_ok) return;
   if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
   bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
@@ -864,14 +618,6 @@ template <int DV, bool DR, bool RG, int NW>
 static void launch_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, float sc_log2, unsigned thr, float dscale,
                        uint64_t seed, hipStream_t s) {
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
-  if constexpr (NW == 8 && DV != 256) {
-    const char* e = getenv("ORBIT2_ATTN_FWD");       // "plain": the un-pipelined 8-wave loop (A/B timing)
-    if (!(e && e[0] == 'p')) {
-      hipLaunchKernelGGL((attn_fwd_pp_kernel<DV, DR, RG>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H,
-                         sc_log2, thr, dscale, seed);
-      return;
-    }
-  }
   hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, RG, NW>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
                      thr, dscale, seed);
 }

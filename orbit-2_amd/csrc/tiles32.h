@@ -45,26 +45,6 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t 
   }
 }
 
-// the same staging through the inline-asm LDS-DMA (common.h: glds16_asm): for kernels that keep a ring of tiles in flight
-// and place every wait themselves
-template <int D, bool RAGGED, int NW>
-__device__ __forceinline__ void stage64_asm(const bf16_t* __restrict__ base, size_t stride, uint32_t tile_lds, int wave,
-                                            int lane, int nvalid) {
-  using C = Cfg<D>;
-  constexpr int NI = C::TILE / 1024;
-  static_assert(NI % NW == 0, "tile pieces must divide over the waves");
-#pragma unroll
-  for (int t = 0; t < NI / NW; ++t) {
-    const int i = wave * (NI / NW) + t;
-    const int row = i * C::RPI + lane / C::CPR;
-    const int cp = lane % C::CPR;
-    const int c = cp ^ swz<D>(row);
-    const int rsrc = (!RAGGED || row < nvalid) ? row : nvalid - 1;
-    const uint32_t off = ((uint32_t)rsrc * (uint32_t)stride + (uint32_t)(c * 8)) * 2u;
-    glds16_asm(base, off, (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile_lds + i * 1024)));
-  }
-}
-
 // row read: 8 consecutive head-dim elements [ds*16 + 8h .. +7] of row `row`
 template <int D>
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int row, int ds, int h) {

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 from climate_learn import _hip
 B, L, H, d = 4, 8192, 24, 128
-for mode in ("pp", "plain4"):
+for mode in ("plain8", "plain4"):
     if mode == "plain4": os.environ["ORBIT2_ATTN_WAVES"] = "4"
     for p in (0.0, 0.1):
         qkv = (torch.randn(B, L, 3, H, d, device="cuda") * 0.5).to(torch.bfloat16)
@@ -22,12 +22,7 @@ for mode in ("pp", "plain4"):
         dd = np.frombuffer(buf, dtype=np.uint32).reshape(64, 8).astype(np.float64)
         nt = dd[0, 7]
         print("attn fwd [%s] B=%d L=%d H=%d d=%d p=%.1f: %.3f ms %.0f TF (stamped build)" % (mode, B, L, H, d, p, ms, 4.0 * B * H * L * L * d / ms / 1e9))
-        if mode == "pp":
-            for g, nm in ((0, "waves 0-3"), (1, "waves 4-7")):
-                v = dd[g::2, :7].mean(0) / nt
-                print("   %s per 64-key tile: X (32 MFMA + fragment reads) %.0f | vmcnt %.0f | barrier %.0f | Y (softmax%s, 4 LDS-DMA) %.0f | barrier %.0f | sum %.0f (loop/nt %.0f); MFMA-only 1024"
-                      % (nm, v[0], v[1], v[2], " + dropout" if p else "", v[3], v[4], v[:5].sum(), v[6]))
-        else:
+        if True:
             v = dd[:, :7].mean(0) / nt
             print("   wave 0 per 64-key tile: stage-issue %.0f | QK^T %.0f | softmax%s %.0f | PV %.0f | vmcnt(0) %.0f | barrier %.0f | sum %.0f (loop/nt %.0f)"
                   % (v[0], v[1], " + dropout" if p else "", v[2], v[3], v[4], v[5], v[:6].sum(), v[6]))
