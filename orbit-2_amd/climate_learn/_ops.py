@@ -345,16 +345,27 @@ class ChainFn(torch.autograd.Function):
             dy = dy.contiguous().to(BF)
         g = _drop_bwd(dy, M, dy.shape[-1], p_out, sds[-1], None, 0)
         grads = [None] * (2 * nl)
+        # the weight gradients of the wide layers go out as ONE grouped launch at the end (alone, a D x D weight gradient is
+        # 144 tiles of 256 x 256: half a round of the chip, so it fell back to the 128-tile kernel at 680 TFLOP/s)
+        dws, queued = _DwBatch(), []
         for i in range(nl - 1, -1, -1):
             W, b = layers[i]
             N, K = W.shape
             h_in = sv[2 * i] if i < nl - 1 else sv[2 * (nl - 1)]
-            grads[2 * i], grads[2 * i + 1] = _dw(g, h_in, W, b, M, N, K)
+            if min(N, K) >= 256:
+                idx, grads[2 * i + 1] = dws.add(g, h_in, W, b, M, N, K)
+                queued.append((i, idx))
+            else:
+                grads[2 * i], grads[2 * i + 1] = _dw(g, h_in, W, b, M, N, K)
             if i > 0:
                 pre_prev = sv[2 * (i - 1) + 1]
                 g = _dx(g, W, M, N, K, drop_p=p_mid, seed=sds[i - 1], dgelu_pre=pre_prev)
             elif has_ln or ctx.needs_input_grad[0]:
                 g = _dx(g, W, M, N, K)
+        if queued:
+            gws = dws.flush()
+            for i, idx in queued:
+                grads[2 * i] = gws[idx]
         out = [None, None]
         if has_ln:
             dx, gg, gb = _ln_bwd(g, x2d, prm[0], prm[1], mean, rstd, None)

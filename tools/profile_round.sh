@@ -1,19 +1,26 @@
 set -e
-# usage (on the GPU box): bash tools/profile_round.sh   -- three rocprofv3 passes of the default bench configuration
+# usage (on the GPU box): bash tools/profile_round.sh [tag]  -- rocprofv3 passes of the default bench configuration
+# (kernel stats; FETCH_SIZE; WRITE_SIZE; MFMA-busy + clock; optional DRAM/MALL counters when the box lists them)
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
+mkdir -p $R/gpurun_out/prof
+rocprofv3 -L > $R/gpurun_out/prof/counters_avail.txt 2>&1 || true
+grep -i -E "dram|mall|EA0_RDREQ|EA0_WRREQ|HBM|TCC_EA" $R/gpurun_out/prof/counters_avail.txt | cut -c1-200 | sort -u | head -60 > $R/gpurun_out/${TAG}_counters_memside.txt || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o ${TAG} -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
 echo stats-done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof -o r01_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof -o ${TAG}_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1
 echo fetch-done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof -o r01_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof -o ${TAG}_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1
 echo write-done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof -o r01_mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof -o ${TAG}_mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_mfma.log 2>&1
 echo mfma-done
 cd $R
-python tools/summarize_prof.py stats gpurun_out/prof/r01_kernel_stats.csv gpurun_out/r01_interm1b_b16_kernel_stats.txt
-python tools/summarize_prof.py pmc gpurun_out/prof/r01_fetch_counter_collection.csv gpurun_out/r01_interm1b_b16_pmc_traffic.txt
-python tools/summarize_prof.py pmc gpurun_out/prof/r01_write_counter_collection.csv gpurun_out/r01_interm1b_b16_pmc_traffic.txt
-python tools/summarize_prof.py traffic gpurun_out/prof/r01_fetch_counter_collection.csv gpurun_out/prof/r01_write_counter_collection.csv gpurun_out/r01_traffic.json 16
-ls gpurun_out/prof
-python tools/summarize_prof.py mfma gpurun_out/prof/r01_mfma_counter_collection.csv gpurun_out/r01_interm1b_b16_mfma_util.txt
+python tools/summarize_prof.py stats gpurun_out/prof/${TAG}_kernel_stats.csv gpurun_out/${TAG}_interm1b_b16_kernel_stats.txt
+rm -f gpurun_out/${TAG}_interm1b_b16_pmc_traffic.txt
+python tools/summarize_prof.py pmc gpurun_out/prof/${TAG}_fetch_counter_collection.csv gpurun_out/${TAG}_interm1b_b16_pmc_traffic.txt
+python tools/summarize_prof.py pmc gpurun_out/prof/${TAG}_write_counter_collection.csv gpurun_out/${TAG}_interm1b_b16_pmc_traffic.txt
+python tools/summarize_prof.py traffic gpurun_out/prof/${TAG}_fetch_counter_collection.csv gpurun_out/prof/${TAG}_write_counter_collection.csv gpurun_out/${TAG}_traffic.json 16
+python tools/summarize_prof.py mfma gpurun_out/prof/${TAG}_mfma_counter_collection.csv gpurun_out/${TAG}_interm1b_b16_mfma_util.txt
+rm -rf gpurun_out/prof/*.csv 2>/dev/null || true
+ls gpurun_out | head -50
