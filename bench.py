@@ -290,6 +290,7 @@ def main():
     drop = 0.0 if a.no_dropout else 0.1
     tp = a.tensor_par
     capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
+    capturable = capturable and not a.daymet       # the perceptual loss reads its upstream gradient on the host
     a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable)
     if tp > 1 and (world % tp or a.graph):
         raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)

@@ -180,6 +180,7 @@ def main():
         hg = tr.get("hipgraph", "auto")
         tokens = batch_size * (in_shape[2] // mc["patch_size"]) * (in_shape[3] // mc["patch_size"])
         capturable = world_size == 1 or dist.get_backend() == "nccl"      # gloo rehearsals stage through the host: no capture
+        capturable = capturable and getattr(train_loss, "graph_capturable", True)
         use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable)) and tp == 1
         gstep, gshape = None, None
         for epoch in range(epoch_start, max_epochs):

@@ -71,6 +71,8 @@ class PERCEPTUAL(Metric):
     Export the real ones on a machine that has the packages:
         import lpips, torch; torch.save(lpips.LPIPS(net='vgg').state_dict(), 'lpips_vgg.pt')"""
 
+    graph_capturable = False      # its backward reads the upstream gradient on the host: no hipGraph capture of this loss
+
     def __init__(self, device, model, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None,
                  synthetic_weights: Optional[bool] = None):
         import os
