@@ -74,6 +74,9 @@ def parse():
                          "reported value counts dp x batch samples per step")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous of the N ranks only (gloo, no GPU call, no workload): checks the self-launch path")
+    ap.add_argument("--fsdp", action="store_true",
+                    help="parameter sharding over the data-parallel ranks (the reference's FSDP FULL_SHARD): per-unit "
+                         "all-gather one unit ahead, reduce-scattered gradients, AdamW on 1/N chunks")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter gradients, AdamW on 1/N of every unit, all-gather the bf16 copies")
     return ap.parse_args()
@@ -290,7 +293,7 @@ def main():
     drop = 0.0 if a.no_dropout else 0.1
     tp = a.tensor_par
     capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
-    capturable = capturable and not a.daymet       # the perceptual loss reads its upstream gradient on the host
+    capturable = capturable and not a.daymet and not a.fsdp     # perceptual loss: host read in backward; fsdp: host-driven gathers
     a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable)
     if tp > 1 and (world % tp or a.graph):
         raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)
@@ -316,8 +319,13 @@ def main():
     for blk in model.blocks:
         blk.recompute = a.recompute
     nparams = sum(p.numel() for p in model.parameters())
-    eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
-                             shard_optimizer=a.shard_optimizer, replica_group=tp_group)
+    if a.fsdp:
+        if tp > 1 or a.graph:
+            raise SystemExit("--fsdp runs without tensor parallelism and without hipGraph replay")
+        eng = cl.HipFullyShardedDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential))
+    else:
+        eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
+                                 shard_optimizer=a.shard_optimizer, replica_group=tp_group)
     opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
     scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0, sync_world=tp > 1)
     loss_fn = Bayesian_TV(aggregate_only=True)
@@ -427,7 +435,8 @@ def main():
                                       B, V, h, w, B, C, 4 * h, 4 * w, hy, wy,
                                       "perceptual (L1 + 0.5 LPIPS-VGG16)" if a.daymet else "bayesian_tv", drop, drop),
                        "per_gpu_batch": B, "global_batch": B * dp_world, "tokens_per_sample": L, "params": nparams,
-                       "parallelism": ("dp%d" % world) if tp == 1 else "dp%dxtp%d" % (dp_world, tp), "activation_recompute": bool(a.recompute),
+                       "parallelism": (("fsdp%d" if a.fsdp else "dp%d") % world) if tp == 1 else "dp%dxtp%d" % (dp_world, tp),
+                       "activation_recompute": bool(a.recompute),
                        "hipgraph": bool(a.graph),
                        "loss": "perceptual" if a.daymet else "bayesian_tv", "in_vars": V},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

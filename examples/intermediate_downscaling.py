@@ -51,13 +51,15 @@ def init_par_groups(world_rank, data_par_size, tensor_par_size, seq_par_size, fs
                     num_heads=None):
     """Reference :161-262.  Rank layout: tensor-parallel ranks are adjacent (fastest varying), data-parallel ranks
     stride by tensor_par_size.  Returns (data_par_group, tensor_par_group); every rank creates every group, in the
-    same order.  The fsdp / simple_ddp split of the data-parallel ranks needs no groups of its own here: `fsdp > 1`
-    selects the sharded-optimizer engine over the whole data-parallel group."""
+    same order.  With fsdp > 1 AND simple_ddp > 1 (HYBRID_SHARD) the data-parallel ranks of a tensor-parallel column are cut
+    as the reference does (:213-241): consecutive runs of fsdp ranks shard a model replica, ranks fsdp apart replicate a
+    shard; the two groups are returned as `init_par_groups.fsdp_group` / `.simple_ddp_group` (None otherwise)."""
     assert seq_par_size == 1, "Sequence parallelism not implemented"
     assert data_par_size * seq_par_size * tensor_par_size == world_size, \
         "DATA_PAR_SIZE * SEQ_PAR_SIZE * TENSOR_PAR_SIZE must equal to world_size"
     if num_heads is not None:
         assert num_heads % tensor_par_size == 0, "model heads % tensor parallel size must be 0"
+    init_par_groups.fsdp_group = init_par_groups.simple_ddp_group = None
     if world_size == 1:
         return None, None
     tensor_par_group = data_par_group = None
@@ -72,6 +74,17 @@ def init_par_groups(world_rank, data_par_size, tensor_par_size, seq_par_size, fs
         group = dist.new_group(ranks)
         if world_rank in ranks:
             data_par_group = group
+        if fsdp_size > 1 and simple_ddp_size > 1:
+            for k in range(simple_ddp_size):
+                fr = ranks[k * fsdp_size:(k + 1) * fsdp_size]
+                g = dist.new_group(fr)
+                if world_rank in fr:
+                    init_par_groups.fsdp_group = g
+            for k in range(fsdp_size):
+                dr = ranks[k::fsdp_size]
+                g = dist.new_group(dr)
+                if world_rank in dr:
+                    init_par_groups.simple_ddp_group = g
     return data_par_group, tensor_par_group
 
 
@@ -152,12 +165,24 @@ def main():
                 cl.utils.load_pretrained_weights(model, str(tr["pretrain"]) + suffix, verbose=world_rank == 0)
             elif tp > 1:                   # from scratch: replicated weights come from the group's first rank (:83-112)
                 cl.dist.tp.sync_replicated(model, tp_group)
-            # parallelism.fsdp > 1 asks the reference for sharded FSDP (HYBRID/FULL_SHARD, :583-617); here it selects the
-            # sharded-optimizer engine (reduce-scatter + AdamW on 1/N + all-gather) over the whole data-parallel group
+            # parallelism.fsdp > 1 asks the reference for sharded FSDP (:609-617): FULL_SHARD over the data-parallel ranks, or
+            # HYBRID_SHARD (shards of `fsdp` ranks, replicated `simple_ddp` times) -> the parameter-sharding engine.
+            # `parallelism.shard_strategy: grad_op` keeps the parameters replicated and shards gradients + optimizer state only
+            # (the SHARD_GRAD_OP-like mode of the NO_SHARD engine); tensor parallelism combines with that mode only.
             shard = fsdp_size > 1 and dp_size > 1
-            print("enter sharded optimizer (SHARD_GRAD_OP-like)," if shard else "enter NO SHARD only,", flush=True)
-            eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
-                                     sync_module_states=True, shard_optimizer=shard, replica_group=tp_group)
+            full = shard and par.get("shard_strategy", "full") == "full" and tp == 1
+            if full:
+                hybrid = ddp_size > 1
+                print("enter hybrid FSDP," if hybrid else "enter fully sharded FSDP,", flush=True)
+                eng = cl.HipFullyShardedDataParallel(
+                    model, process_group=init_par_groups.fsdp_group if hybrid else dp_group, unit_types=(Block, nn.Sequential),
+                    sync_module_states=True, replicate_group=init_par_groups.simple_ddp_group if hybrid else None)
+                if world_rank == 0:
+                    print("per-rank parameter bytes:", eng.param_bytes_per_rank(), flush=True)
+            else:
+                print("enter sharded optimizer (SHARD_GRAD_OP-like)," if shard else "enter NO SHARD only,", flush=True)
+                eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
+                                         sync_module_states=True, shard_optimizer=shard, replica_group=tp_group)
             for blk in model.blocks:
                 blk.recompute = bool(tr.get("activation_checkpointing", False))
             optimizer = cl.load_optimizer(eng, "adamw", {"lr": float(mc["lr"]), "weight_decay": float(mc["weight_decay"]),
@@ -181,6 +206,7 @@ def main():
         tokens = batch_size * (in_shape[2] // mc["patch_size"]) * (in_shape[3] // mc["patch_size"])
         capturable = world_size == 1 or dist.get_backend() == "nccl"      # gloo rehearsals stage through the host: no capture
         capturable = capturable and getattr(train_loss, "graph_capturable", True)
+        capturable = capturable and not getattr(eng, "shard_params", False)    # gathers / releases are host-driven
         use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable)) and tp == 1
         gstep, gshape = None, None
         for epoch in range(epoch_start, max_epochs):

@@ -13,6 +13,7 @@ _FACTORIES = ("load_model_module load_forecasting_module load_climatebench_modul
 globals().update({_n: getattr(_loaders, _n) for _n in _FACTORIES})
 from . import data
 from .dist.dp_engine import HipDataParallel
+from .dist.fsdp_engine import HipFullyShardedDataParallel
 from .optim import HipAdamW, HipGradScaler
 from ._ops import manual_seed
 from .graphs import GraphedTrainStep

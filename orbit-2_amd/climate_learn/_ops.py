@@ -73,7 +73,44 @@ def cw(p: torch.Tensor) -> torch.Tensor:
     c = getattr(p, "_o2c", None)
     if c is not None:
         return c
+    if getattr(p, "_o2_sharded", False):
+        raise RuntimeError("parameter of a sharded unit used while its unit is not gathered (dist/fsdp_engine.py)")
     return _hip.cast_to_bf16(p.detach().contiguous())
+
+
+# ------------------------------------------------------------------------------------------------------
+# unit scopes: a parameter-sharding engine (dist/fsdp_engine.py, the reference's FSDP FULL / HYBRID_SHARD) gathers a
+# unit's bf16 parameters right before the unit's forward and again right before its backward.  Modules whose parameters
+# form a unit bracket their fused op with unit_enter / unit_exit; without such an engine both are free.
+# ------------------------------------------------------------------------------------------------------
+class _UnitBackwardGate(torch.autograd.Function):
+    """identity; its backward runs BEFORE the unit's own backward (it sits downstream of the unit in the graph)"""
+
+    @staticmethod
+    def forward(ctx, x, mod):
+        ctx.mod = mod
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = getattr(ctx.mod, "_o2_unit_engine", None)
+        if eng is not None:
+            eng.pre_backward(ctx.mod)
+        return g, None
+
+
+def unit_enter(mod):
+    eng = getattr(mod, "_o2_unit_engine", None)
+    if eng is not None:
+        eng.pre_forward(mod)
+
+
+def unit_exit(mod, out):
+    eng = getattr(mod, "_o2_unit_engine", None)
+    if eng is None:
+        return out
+    eng.post_forward(mod)
+    return _UnitBackwardGate.apply(out, mod) if torch.is_grad_enabled() and out.requires_grad else out
 
 
 class _GradSink:

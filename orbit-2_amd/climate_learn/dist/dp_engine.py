@@ -131,8 +131,10 @@ class HipDataParallel(nn.Module):
             bk = Bucket(uname)
             s32, s16 = o32, o16
             rep16 = rep32 = 0                       # length of the replicated prefix of the bf16 / fp32 range
+            lo_members, hi_members = [], []         # (param, offset inside the unit's range, numel): checkpoint layout
             for n, p in lo:
                 k = p.numel()
+                lo_members.append((p, o16 - s16, k))
                 if not hasattr(p, "_o2_tp"):
                     rep16 = o16 - s16 + _round_up(k)
                 self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
@@ -157,13 +159,15 @@ class HipDataParallel(nn.Module):
                 if self.shard:
                     ck = n_lo // self.world
                     self.opt_segments.append(dict(kind="lo", o32=s32 + self.rank * ck, og=s16 + self.rank * ck, n=ck,
-                                                  os=self.opt_state_size))
+                                                  os=self.opt_state_size, gather=True, members=lo_members))
                     self.opt_state_size += ck
                 else:
-                    self.opt_segments.append(dict(kind="lo", o32=s32, og=s16, n=n_lo, os=s32))
+                    self.opt_segments.append(dict(kind="lo", o32=s32, og=s16, n=n_lo, os=s32, gather=False,
+                                                  members=lo_members))
             s32h, sg = o32, og32
             for n, p in hi:
                 k = p.numel()
+                hi_members.append((p, og32 - sg, k))
                 if not hasattr(p, "_o2_tp"):
                     rep32 = og32 - sg + _round_up(k)
                 self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
@@ -179,15 +183,25 @@ class HipDataParallel(nn.Module):
                 self.hi_ranges.append((s32h, sg, og32 - sg))
                 bk.grad_views.append(self.g32[sg:og32])
                 if self.shard:
-                    self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=self.opt_state_size))
+                    self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=self.opt_state_size,
+                                                  gather=False, members=hi_members))
                     self.opt_state_size += og32 - sg
                 else:
-                    self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=s32h))
+                    self.opt_segments.append(dict(kind="hi", o32=s32h, og=sg, n=og32 - sg, os=s32h, gather=False,
+                                                  members=hi_members))
             if self.replica_group is not None:
                 bk.rep_views = [v for v in (self.g16[s16:s16 + rep16], self.g32[sg:sg + rep32]) if v.numel()]
             self.buckets.append(bk)
         if not self.shard:
-            self.opt_state_size = n32                      # moments laid out like flat32 (checkpoint format)
+            self.opt_state_size = n32                      # moments laid out like flat32
+        # what the optimizer / loss scaler touch, as tensors (the same dict shape as the parameter-sharding engine's):
+        # p32 fp32 master range, g gradient range, p16 bf16 compute range (None for fp32-compute parameters)
+        for sg_ in self.opt_segments:
+            lo_ = sg_["kind"] == "lo"
+            sg_["p32"] = self.flat32[sg_["o32"]:sg_["o32"] + sg_["n"]]
+            sg_["g"] = (self.g16 if lo_ else self.g32)[sg_["og"]:sg_["og"] + sg_["n"]]
+            sg_["p16"] = self.flat16[sg_["og"]:sg_["og"] + sg_["n"]] if lo_ else None
+        self.grad_world = self.world                       # number of ranks whose gradients are summed (AdamW divides)
         self.refresh_compute_copies()
         if sync_module_states and (self.world > 1 or self.force_comm):
             dist.broadcast(self.flat32, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0,
@@ -266,6 +280,14 @@ class HipDataParallel(nn.Module):
             ck = n // self.world
             mine = flat[off + self.rank * ck: off + (self.rank + 1) * ck]
             dist.all_gather_into_tensor(flat[off:off + n], mine if inplace else mine.clone(), group=self.pg)
+
+    def gather_range(self, chunk: torch.Tensor) -> torch.Tensor:
+        """the full range a rank-chunk belongs to (ranks' chunks concatenated in rank order); used for checkpoints"""
+        if self.world == 1 and not self.force_comm:
+            return chunk
+        full = torch.empty(chunk.numel() * self.world, dtype=chunk.dtype, device=chunk.device)
+        dist.all_gather_into_tensor(full, chunk.contiguous().clone(), group=self.pg)
+        return full
 
     def gather_params(self):
         """sharded optimizer: after the local AdamW, collect every rank's updated bf16 compute chunk"""

@@ -199,7 +199,8 @@ class Res_Slim_ViT(nn.Module):
         for m in self.head:
             if isinstance(m, HipLinear):
                 prm += [m.weight, m.bias]
-        t = _ops.ChainFn.apply(t, {"ln": True}, *prm)
+        _ops.unit_enter(self.head)
+        t = _ops.unit_exit(self.head, _ops.ChainFn.apply(t, {"ln": True}, *prm))
         img = self.unpatchify(t, scaling=self.superres_mag, out_channels=self.out_channels)
         co = self.conv_out
         return _ops.Conv3x3Fn.apply(img, co.weight, co.bias, None, 0, 1, r)

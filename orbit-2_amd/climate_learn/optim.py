@@ -31,9 +31,9 @@ class HipAdamW(torch.optim.Optimizer):
         if engine is not None:
             # moments cover what this rank updates: everything (flat32 layout), or with a sharded optimizer its chunk
             # of every unit's bf16 range plus the replicated fp32-compute parameters
-            self.m = torch.zeros(engine.opt_state_size, dtype=F32, device=engine.flat32.device)
-            self.v = torch.zeros(engine.opt_state_size, dtype=F32, device=engine.flat32.device)
-            self.found_inf = torch.zeros(1, dtype=F32, device=engine.flat32.device)
+            self.m = torch.zeros(engine.opt_state_size, dtype=F32, device=engine.device)
+            self.v = torch.zeros(engine.opt_state_size, dtype=F32, device=engine.device)
+            self.found_inf = torch.zeros(1, dtype=F32, device=engine.device)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,16 +43,12 @@ class HipAdamW(torch.optim.Optimizer):
         if self.engine is not None:
             e = self.engine
             e.finish_grad_sync()
-            gs = self.grad_scale / e.world
+            gs = self.grad_scale / e.grad_world
             fi = self.found_inf if self.check_inf else None
             for sg in e.opt_segments:
-                o32, og, n, os_ = sg["o32"], sg["og"], sg["n"], sg["os"]
-                if sg["kind"] == "lo":
-                    _hip.adamw(e.flat32[o32:], self.m[os_:], self.v[os_:], e.g16[og:], e.flat16[og:], n, lr, b1, b2, eps,
-                               wd, self._step, gs, fi)
-                else:
-                    _hip.adamw(e.flat32[o32:], self.m[os_:], self.v[os_:], e.g32[og:], None, n, lr, b1, b2, eps, wd,
-                               self._step, gs, fi)
+                n, os_ = sg["n"], sg["os"]
+                _hip.adamw(sg["p32"], self.m[os_:], self.v[os_:], sg["g"], sg["p16"], n, lr, b1, b2, eps, wd, self._step,
+                           gs, fi)
             e.gather_params()
             return None
         # un-managed parameters (unit tests / tiny models): one launch per tensor
@@ -86,13 +82,29 @@ class HipAdamW(torch.optim.Optimizer):
     def _params(self):
         return [p for g in self.param_groups for p in g["params"]]
 
-    def _offset32(self, p) -> int:
+    def _moments_per_param(self, st):
+        """{id(param): tensor of the parameter's shape} from a moment buffer laid out like the engine's optimizer segments
+        (a segment that is a rank's 1/N chunk of a range is all-gathered first: a collective in the sharded modes)"""
+        out = {}
+        for sg in self.engine.opt_segments:
+            rng = st[sg["os"]:sg["os"] + sg["n"]]
+            if sg["gather"]:
+                rng = self.engine.gather_range(rng)
+            for p, off, k in sg["members"]:
+                out[id(p)] = rng[off:off + k].view(p.shape)
+        return out
+
+    def _load_moments_per_param(self, st, per_param):
+        """the inverse: per_param maps id(param) -> full tensor (or is missing: zeros)"""
         e = self.engine
-        off = p.data.storage_offset() - e.flat32.storage_offset()
-        if p.data.untyped_storage().data_ptr() != e.flat32.untyped_storage().data_ptr() or off < 0 \
-                or off + p.numel() > e.flat32.numel():
-            raise RuntimeError("parameter is not a view of the engine's flat master buffer")
-        return off
+        for sg in e.opt_segments:
+            n = sg["n"]
+            full = torch.zeros(n * (e.world if sg["gather"] else 1), dtype=F32, device=st.device)
+            for p, off, k in sg["members"]:
+                t = per_param.get(id(p))
+                if t is not None:
+                    full[off:off + k].copy_(t.reshape(-1).to(st.device, F32))
+            st[sg["os"]:sg["os"] + n].copy_(full[e.rank * n:(e.rank + 1) * n] if sg["gather"] else full)
 
     def state_dict(self):
         if self.engine is None:
@@ -103,38 +115,14 @@ class HipAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(float(self._step))
             sd["orbit2"] = {"step": self._step, "format": 2}
             return sd
-        fm, fv = self._full_state(self.m), self._full_state(self.v)
+        pm, pv = self._moments_per_param(self.m), self._moments_per_param(self.v)
         state, idx = {}, []
         for i, p in enumerate(self._params()):
-            off, n = self._offset32(p), p.numel()
-            state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": fm[off:off + n].view(p.shape),
-                        "exp_avg_sq": fv[off:off + n].view(p.shape)}
+            state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": pm[id(p)], "exp_avg_sq": pv[id(p)]}
             idx.append(i)
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
         groups[0]["params"] = idx
         return {"state": state, "param_groups": groups, "orbit2": {"step": self._step, "format": 2}}
-
-    def _full_state(self, st):
-        """moments in the flat32 layout of THIS engine (sharded: gathered from the ranks' chunks)"""
-        e = self.engine
-        if not e.shard:
-            return st
-        full = torch.zeros_like(e.flat32)
-        for sg in e.opt_segments:
-            full[sg["o32"]:sg["o32"] + sg["n"]].copy_(st[sg["os"]:sg["os"] + sg["n"]])
-        e._gather_ranges(full, 0)
-        return full
-
-    def _load_full_state(self, st, full):
-        e = self.engine
-        if full.numel() != e.flat32.numel():
-            raise RuntimeError("optimizer moments of %d elements do not fit this engine's layout (%d)"
-                               % (full.numel(), e.flat32.numel()))
-        if not e.shard:
-            st.copy_(full)
-            return
-        for sg in e.opt_segments:
-            st[sg["os"]:sg["os"] + sg["n"]].copy_(full[sg["o32"]:sg["o32"] + sg["n"]])
 
     def load_state_dict(self, sd):
         sd = dict(sd)                                    # the caller's dict is left as it was
@@ -149,14 +137,8 @@ class HipAdamW(torch.optim.Optimizer):
         for g, sg in zip(self.param_groups, sd.get("param_groups", [])):       # hyper-parameters (lr schedule position)
             g.update({k: v for k, v in sg.items() if k != "params"})
         if extra and "m" in extra:
-            # round-1 format: flat moments in the WRITING engine's layout -- only valid for an identical layout
-            if extra["m"].numel() != self.engine.flat32.numel() or self.engine.shard:
-                raise RuntimeError("this checkpoint holds flat optimizer moments in its writer's layout (round-1 format); "
-                                   "load it with the same engine mode and world size, then re-save")
-            self._load_full_state(self.m, extra["m"].to(self.m.device))
-            self._load_full_state(self.v, extra["v"].to(self.v.device))
-            self._step = extra["step"]
-            return
+            raise RuntimeError("this checkpoint holds flat optimizer moments in its writer's buffer layout (round-1 format): "
+                               "not loadable; re-save it with the current code")
         state = sd.get("state", {})
         params = self._params()
         if not state:
@@ -164,8 +146,7 @@ class HipAdamW(torch.optim.Optimizer):
             warnings.warn("optimizer checkpoint holds no per-parameter state: AdamW moments and step count start from zero")
             self._step = extra["step"] if extra else 0
             return
-        fm, fv = torch.zeros_like(self.engine.flat32), torch.zeros_like(self.engine.flat32)
-        steps = []
+        pm, pv, steps = {}, {}, []
         for i, p in enumerate(params):
             st = state.get(i, state.get(str(i)))
             if st is None:
@@ -173,12 +154,10 @@ class HipAdamW(torch.optim.Optimizer):
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise RuntimeError("optimizer state %d has shape %s, parameter has %s"
                                    % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
-            off, n = self._offset32(p), p.numel()
-            fm[off:off + n].copy_(st["exp_avg"].reshape(-1).to(fm.device, F32))
-            fv[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(fv.device, F32))
+            pm[id(p)], pv[id(p)] = st["exp_avg"], st["exp_avg_sq"]
             steps.append(float(st["step"]))
-        self._load_full_state(self.m, fm)
-        self._load_full_state(self.v, fv)
+        self._load_moments_per_param(self.m, pm)
+        self._load_moments_per_param(self.v, pv)
         self._step = int(extra["step"]) if extra else (int(max(steps)) if steps else 0)
 
 
@@ -209,11 +188,12 @@ class HipGradScaler:
         fi = optimizer.found_inf
         fi.zero_()
         for sg in eng.opt_segments:       # with a sharded optimizer: this rank's reduced chunk of every bf16 bucket
-            _hip.check_finite((eng.g16 if sg["kind"] == "lo" else eng.g32)[sg["og"]:], sg["n"], fi)
+            _hip.check_finite(sg["g"], sg["n"], fi)
         if self.sync_world and dist.is_initialized() and dist.get_world_size() > 1:
             _tp.all_reduce_max(fi, None)
-        elif eng.world > 1:
-            dist.all_reduce(fi, op=dist.ReduceOp.MAX, group=eng.pg)
+        elif getattr(eng, "grad_world", eng.world) > 1:
+            for grp in getattr(eng, "found_inf_groups", [eng.pg]):     # shard group, then (HYBRID) the replica group
+                dist.all_reduce(fi, op=dist.ReduceOp.MAX, group=grp)
         optimizer.grad_scale = 1.0 / self._scale
         optimizer.check_inf = True
         optimizer.step()            # the kernel skips the update on device when found_inf != 0

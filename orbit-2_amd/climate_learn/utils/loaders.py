@@ -60,7 +60,7 @@ def load_optimizer(net: torch.nn.Module, optim: str, optim_kwargs: Dict[str, Any
         return None
     if optim.lower() != "adamw":
         raise NotImplementedError(_issue("optimizer", optim))
-    engine = net if hasattr(net, "lowp_ranges") else None
+    engine = net if hasattr(net, "opt_segments") else None          # either data-parallel engine (dist/dp_engine.py, dist/fsdp_engine.py)
     return HipAdamW(net.parameters(), engine=engine, **optim_kwargs)
 
 

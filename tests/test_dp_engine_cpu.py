@@ -213,14 +213,10 @@ def _worker_optim_ckpt(rank, world, port, q):
         ms, es, os_ = make(True)
         mr, er, or_ = make(False)
         assert es.flat32.numel() != er.flat32.numel()          # the sharded layout is padded: offsets differ
-        # put known moments into the SHARDED optimizer (each rank holds its chunks only)
-        fm, fv = torch.zeros_like(es.flat32), torch.zeros_like(es.flat32)
-        for i, p in enumerate(ms.parameters()):
-            off = os_._offset32(p)
-            fm[off:off + p.numel()] = expected(p, i, 0).reshape(-1)
-            fv[off:off + p.numel()] = expected(p, i, 1).reshape(-1)
-        os_._load_full_state(os_.m, fm)
-        os_._load_full_state(os_.v, fv)
+        # put known moments into the SHARDED optimizer (each rank keeps its chunks only)
+        os_._load_moments_per_param(os_.m, {id(p): expected(p, i, 0) for i, p in enumerate(ms.parameters())})
+        os_._load_moments_per_param(os_.v, {id(p): expected(p, i, 1) for i, p in enumerate(ms.parameters())})
+        assert os_.m.numel() < or_.m.numel()                   # 1/2 of every unit's bf16 range + the replicated rest
         os_._step = 11
         sd = os_.state_dict()                                  # collective: gathers the ranks' chunks
         assert sd["orbit2"]["step"] == 11 and len(sd["state"]) == len(list(ms.parameters()))
@@ -231,10 +227,9 @@ def _worker_optim_ckpt(rank, world, port, q):
         # sharded (world 2) -> replicated
         or_.load_state_dict(sd)
         assert or_._step == 11 and "orbit2" in sd
+        gm, gv = or_._moments_per_param(or_.m), or_._moments_per_param(or_.v)
         for i, p in enumerate(mr.parameters()):
-            off = or_._offset32(p)
-            assert torch.equal(or_.m[off:off + p.numel()].view(p.shape), expected(p, i, 0))
-            assert torch.equal(or_.v[off:off + p.numel()].view(p.shape), expected(p, i, 1))
+            assert torch.equal(gm[id(p)], expected(p, i, 0)) and torch.equal(gv[id(p)], expected(p, i, 1))
         # ... and back into a fresh sharded optimizer
         ms2, es2, os2 = make(True)
         os2.load_state_dict(or_.state_dict())
@@ -306,3 +301,146 @@ def test_skipped_step_does_not_advance_bias_correction():
     assert sc.update() is True and _Opt._step == 4 and sc.get_scale() == 512.0
     sc._found, sc._opt = torch.tensor([0.0]), _Opt
     assert sc.update() is False and _Opt._step == 4
+
+
+def _worker_fsdp(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import climate_learn as cl
+        from climate_learn import _ops
+        from climate_learn.models.hub.components.vit_blocks import Block
+        torch.manual_seed(100 + rank)                # different init per rank: rank 0's weights must win in both engines
+        m_rep = _build()
+        torch.manual_seed(100 + rank)
+        m_fs = _build()
+        rep = cl.HipDataParallel(m_rep, unit_types=(Block, nn.Sequential), overlap=False)
+        fs = cl.HipFullyShardedDataParallel(m_fs, unit_types=(Block, nn.Sequential))
+        names = [u.name for u in fs.units]
+        assert names == ["blocks.0", "blocks.1", "path2", "head", "root"], names
+        assert [u.name for u in fs.sharded_units] == ["blocks.0", "blocks.1", "head"]
+        by = fs.param_bytes_per_rank()
+        # a rank keeps 1/world of every sharded unit (up to the 128-element padding)
+        sh_elems = sum(u.n for u in fs.sharded_units)
+        assert by["sharded_units"] == 8 * sh_elems // world and by["sharded_units"] + by["resident"] < by["replicated_engine_would_keep"]
+        pr = dict(m_rep.named_parameters())
+        pf = dict(m_fs.named_parameters())
+        # 1. forward: a unit is whole exactly between unit_enter and unit_exit, bit-equal to the replicated compute copy
+        w = m_fs.blocks[1].mlp.fc1.weight
+        try:
+            _ops.cw(w)
+            raise AssertionError("sharded parameter readable outside its unit scope")
+        except RuntimeError:
+            pass
+        for uname in ("blocks.0", "blocks.1", "head"):
+            mod = m_fs.get_submodule(uname)
+            _ops.unit_enter(mod)
+            lowp = [(n, p) for n, p in mod.named_parameters() if getattr(p, "_o2_sharded", False)]
+            assert len(lowp) == len(mod._o2_unit.members) > 0
+            for n, p in lowp:
+                assert torch.equal(p._o2c, pr[uname + "." + n]._o2c), (uname, n)
+            out = _ops.unit_exit(mod, torch.zeros(1))
+            assert all(p._o2c is None for _, p in lowp)
+        assert fs._order == fs.sharded_units and len(fs._pfree) == 3         # every pooled buffer came back
+        # 2. backward (simulated kernels): rank-dependent gradients; reduce-scatter leaves this rank's chunk of the sum
+        rep.zero_grad()
+        fs.zero_grad()
+        for uname in ("head", "blocks.1", "blocks.0"):
+            mod = m_fs.get_submodule(uname)
+            fs.pre_backward(mod)
+            lowp = [(n, p) for n, p in mod.named_parameters() if getattr(p, "_o2_sharded", False)]
+            for n, p in lowp:
+                q_ = pr[uname + "." + n]
+                val = (torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) % 13 + rank + 1).to(torch.bfloat16)
+                p._o2g.copy_(val)
+                q_._o2g.copy_(val)
+                p._o2_fresh = q_._o2_fresh = False
+            for n, p in lowp:
+                fs.grad_ready(p)
+                rep.grad_ready(pr[uname + "." + n])
+            assert all(p._o2g is None and p._o2c is None for _, p in lowp)     # buffers released at launch
+        for n, p in pf.items():                      # the resident rest: root unit + fp32-compute parameters
+            if getattr(p, "_o2_sharded", False) or not p.requires_grad:
+                continue
+            q_ = pr[n]
+            if hasattr(p, "_o2g") and p._o2g is not None:
+                p._o2g.fill_(float(rank + 1)); q_._o2g.fill_(float(rank + 1))
+                p._o2_fresh = q_._o2_fresh = False
+                fs.grad_ready(p); rep.grad_ready(q_)
+            else:
+                p.grad.add_(0.5 * (rank + 1)); q_.grad.add_(0.5 * (rank + 1))
+                fs._hi_hook(p); rep._hi_hook(q_)
+        fs.finish_grad_sync()
+        rep.finish_grad_sync()
+        for u in fs.sharded_units:
+            mine = fs.gchunk16[u.cs:u.cs + u.ck]
+            for p, off, k in u.members:              # compare on the part of every parameter that lies in this rank's chunk
+                lo, hi = max(off, rank * u.ck), min(off + k, (rank + 1) * u.ck)
+                if lo < hi:
+                    name = [n for n, pp in pf.items() if pp is p][0]
+                    ref = pr[name]._o2g.reshape(-1)[lo - off:hi - off]
+                    assert torch.equal(mine[lo - rank * u.ck:hi - rank * u.ck], ref), name
+        assert torch.equal(m_fs.conv_out.weight.grad, m_rep.conv_out.weight.grad)
+        assert torch.equal(m_fs.norm.weight._o2g, m_rep.norm.weight._o2g)
+        # 3. a stand-in update of the chunks shows up in the next gather on every rank
+        for sg in fs.opt_segments:
+            if sg["kind"] == "lo":
+                sg["p32"].add_(1.0 + rank)
+                sg["p16"].copy_(sg["p32"])
+        fs.gather_params()
+        mod = m_fs.blocks[0]
+        _ops.unit_enter(mod)
+        u = mod._o2_unit
+        for n, p in mod.named_parameters():          # every element moved by 1 + (the rank that owns its chunk)
+            if not getattr(p, "_o2_sharded", False):
+                continue
+            off = [o for pp, o, _ in u.members if pp is p][0]
+            owner = ((off + torch.arange(p.numel())) // u.ck).reshape(p.shape).float()
+            want = (pr["blocks.0." + n].data + (1.0 + owner)).to(torch.bfloat16)
+            assert torch.equal(p._o2c, want), n
+        _ops.unit_exit(mod, torch.zeros(1))
+        # 4. full fp32 state dict (collective) with the reference's keys; load round trip; per-parameter optimizer state
+        sd = fs.state_dict()
+        assert set(sd) == set(rep.state_dict()) and all(v.dtype == torch.float32 for v in sd.values())
+        assert tuple(sd["blocks.1.mlp.fc1.weight"].shape) == tuple(w.shape) and float(sd["blocks.1.mlp.fc1.weight"].abs().sum()) > 0
+        both = [None] * world
+        dist.all_gather_object(both, {k: float(v.double().sum()) for k, v in sd.items()})
+        assert both[0] == both[1]                    # every rank assembled the same full dict
+        sd2 = {k: v + 0.25 for k, v in sd.items()}
+        fs.load_state_dict(sd2)
+        sd3 = fs.state_dict()
+        assert all(torch.equal(sd3[k], sd2[k]) for k in sd2)
+        opt = cl.load_optimizer(fs, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+        assert opt.m.numel() == fs.opt_state_size < sum(p.numel() for p in m_fs.parameters())
+        opt._load_moments_per_param(opt.m, {id(p): torch.full(p.shape, float(i)) for i, p in enumerate(m_fs.parameters())})
+        osd = opt.state_dict()
+        for i, p in enumerate(m_fs.parameters()):
+            assert torch.all(osd["state"][i]["exp_avg"] == float(i)) and osd["state"][i]["exp_avg"].shape == p.shape
+        ropt = cl.load_optimizer(rep, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+        ropt.load_state_dict(osd)                    # a parameter-sharded checkpoint loads into the replicated engine
+        gm = ropt._moments_per_param(ropt.m)
+        assert all(torch.all(gm[id(p)] == float(i)) for i, p in enumerate(m_rep.parameters()))
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_fully_sharded_engine_world2_gloo():
+    """SURVEY 8f-4 / reference FSDP FULL_SHARD (examples/intermediate_downscaling.py:609-617): parameters of every Block and
+    of the head live as 1/N chunks; gathered units are bit-equal to the replicated engine's compute copies, reduce-scattered
+    gradient chunks equal its all-reduced buckets, checkpoints are full and layout-independent"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fsdp, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res

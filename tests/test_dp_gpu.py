@@ -106,3 +106,70 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(shard):
         p.join(60)
     for r in res:
         assert r[1] == "ok", "rank %d:\n%s" % (r[0], r[1])
+
+
+def test_fully_sharded_engine_matches_replicated_engine(golden_dir, monkeypatch):
+    """SURVEY 8f-4 (reference FSDP FULL_SHARD, examples/intermediate_downscaling.py:609-617) on the GPU with the collectives
+    forced on over a single-rank RCCL group: units gathered one ahead on the communication stream, gradients
+    reduce-scattered from pooled buffers, AdamW on the chunks.  After ONE step the parameters of every Block and of the head
+    are bit-identical to the replicated engine's (their gradients do not pass through the atomically accumulated
+    variable-aggregation backward); three steps keep the two loss trajectories together; the full state dict round-trips."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    import climate_learn as cl
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    from tests.test_model_gpu import load, VW
+    monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29657")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        eng, opt, scl, traj = {}, {}, {}, {"rep": [], "fsdp": []}
+        for mode in ("rep", "fsdp"):
+            c, z, sd, m = load(golden_dir, "v5c1_hd64")
+            m.train()
+            eng[mode] = (cl.HipFullyShardedDataParallel if mode == "fsdp" else cl.HipDataParallel)(
+                m, unit_types=(Block, nn.Sequential))
+            opt[mode] = cl.load_optimizer(eng[mode], "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+            scl[mode] = cl.HipGradScaler(init_scale=1024.0)
+        f = eng["fsdp"]
+        assert f.comm and [u.name for u in f.sharded_units] == ["blocks.0", "blocks.1", "head"]
+        x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+        loss_fn = Bayesian_TV(aggregate_only=True)
+        for step in range(3):
+            for mode in ("rep", "fsdp"):
+                cl.manual_seed(step)                         # the same dropout / DropPath masks in both engines
+                loss = training_step((x, y, c["in_vars"], c["out_vars"]), step, eng[mode], torch.device("cuda"), VW, loss_fn)
+                opt[mode].zero_grad()
+                scl[mode].scale(loss).backward()
+                scl[mode].step(opt[mode])
+                assert scl[mode].update() is False
+                traj[mode].append(float(loss))
+            if step == 0:
+                assert traj["rep"][0] == traj["fsdp"][0]     # same weights, same masks: the same forward
+                a, b = eng["rep"].state_dict(), f.state_dict()
+                assert set(a) == set(b)
+                for k in a:
+                    if k.startswith("blocks.") or k.startswith("head."):
+                        assert torch.equal(a[k], b[k]), k
+                    else:
+                        assert torch.allclose(a[k], b[k], rtol=0, atol=2e-3), k      # +-lr on atomically summed gradients
+        assert all(abs(p - q) / p < 2e-3 for p, q in zip(traj["rep"], traj["fsdp"])), traj
+        assert len(f._pfree) == 3 and len(f._gfree) == 2        # every pooled buffer came back
+        with torch.no_grad():                                   # eval forward through the sharded engine
+            f.eval()
+            pred = f(x.cuda(), c["in_vars"], c["out_vars"])
+        assert torch.isfinite(pred).all()
+        sdf = f.state_dict()
+        f.load_state_dict({k: v.clone() for k, v in sdf.items()})
+        sdf2 = f.state_dict()
+        assert all(torch.equal(sdf[k], sdf2[k]) for k in sdf)
+        by = f.param_bytes_per_rank()
+        assert by["sharded_units"] > 0 and by["optimizer_state"] == 8 * f.opt_state_size
+    finally:
+        if created:
+            dist.destroy_process_group()

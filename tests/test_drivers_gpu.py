@@ -249,14 +249,18 @@ def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path, ddp):
     assert re.findall(r"epoch:  (\d+) batch_idx 0 ", out2) == ["2"]
 
 
-@pytest.mark.parametrize("mode", ["simple_ddp", "fsdp"])
+@pytest.mark.parametrize("mode", ["simple_ddp", "fsdp", "grad_op"])
 def test_training_driver_two_data_parallel_ranks_one_card(tmp_path, mode):
-    """the multi-rank data-parallel control flow on GPU tensors (bucket all-reduce / sharded optimizer on the side stream,
-    found_inf agreement, rank-0 checkpoint) with two ranks sharing the box's card over gloo; RCCL itself needs one GPU per
-    rank and is exercised by the round-end scaling run"""
+    """the multi-rank data-parallel control flow on GPU tensors with two ranks sharing the box's card over gloo (RCCL itself
+    needs one GPU per rank and is exercised by the round-end scaling run): NO_SHARD bucket all-reduce (simple_ddp: 2),
+    parameter sharding = the reference's FSDP FULL_SHARD (fsdp: 2: per-unit all-gather / reduce-scatter, chunked AdamW,
+    full state dict on rank 0), and the gradient / optimizer-state sharding mode (shard_strategy: grad_op)"""
     conf = yaml.safe_load(open(os.path.join(ROOT, "configs", "interm_8m.yaml")))
     conf["trainer"].update(max_epochs=2, batch_size=2)
-    conf["parallelism"].update(**{"simple_ddp": 1, "fsdp": 1, mode: 2})
+    key = "fsdp" if mode == "grad_op" else mode
+    conf["parallelism"].update(**{"simple_ddp": 1, "fsdp": 1, key: 2})
+    if mode == "grad_op":
+        conf["parallelism"]["shard_strategy"] = "grad_op"
     conf["model"].update(depth=2, warmup_epochs=1)
     conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=3)
     cfg = os.path.join(tmp_path, "dp.yaml")
@@ -271,7 +275,8 @@ def test_training_driver_two_data_parallel_ranks_one_card(tmp_path, mode):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, o[-1500:] + e[-3000:]
     out = outs[0][0]
-    assert ("enter sharded optimizer" in out) == (mode == "fsdp")
+    assert ("enter sharded optimizer" in out) == (mode == "grad_op")
+    assert ("enter fully sharded FSDP" in out and "per-rank parameter bytes" in out) == (mode == "fsdp")
     losses = [float(m) for m in re.findall(r"world_rank 0  loss  ([0-9.eE+-]+)", out)]
     assert len(losses) == 6 and all(l == l and 0 < l < 1e4 for l in losses)
     ck = torch.load(os.path.join(tmp_path, "checkpoints", "climate", "interm_epoch_1.ckpt"), map_location="cpu")
