@@ -84,25 +84,30 @@ def cw(p: torch.Tensor) -> torch.Tensor:
 # form a unit bracket their fused op with unit_enter / unit_exit; without such an engine both are free.
 # ------------------------------------------------------------------------------------------------------
 class _UnitBackwardGate(torch.autograd.Function):
-    """identity; its backward runs BEFORE the unit's own backward (it sits downstream of the unit in the graph)"""
+    """identity.  On a unit's OUTPUT (last = False) its backward runs before the unit's own backward (it sits downstream of
+    the unit in the graph): the engine gathers the unit.  On the unit's INPUT (last = True) it runs after the unit's
+    backward has returned: the engine takes the gathered parameters back."""
 
     @staticmethod
-    def forward(ctx, x, mod):
-        ctx.mod = mod
+    def forward(ctx, x, mod, last):
+        ctx.mod, ctx.last = mod, last
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         eng = getattr(ctx.mod, "_o2_unit_engine", None)
         if eng is not None:
-            eng.pre_backward(ctx.mod)
-        return g, None
+            (eng.post_backward if ctx.last else eng.pre_backward)(ctx.mod)
+        return g, None, None
 
 
-def unit_enter(mod):
+def unit_enter(mod, x):
+    """call with the unit's input right before its fused op; returns the input to use"""
     eng = getattr(mod, "_o2_unit_engine", None)
-    if eng is not None:
-        eng.pre_forward(mod)
+    if eng is None:
+        return x
+    eng.pre_forward(mod)
+    return _UnitBackwardGate.apply(x, mod, True) if torch.is_grad_enabled() and x.requires_grad else x
 
 
 def unit_exit(mod, out):
@@ -110,7 +115,7 @@ def unit_exit(mod, out):
     if eng is None:
         return out
     eng.post_forward(mod)
-    return _UnitBackwardGate.apply(out, mod) if torch.is_grad_enabled() and out.requires_grad else out
+    return _UnitBackwardGate.apply(out, mod, False) if torch.is_grad_enabled() and out.requires_grad else out
 
 
 class _GradSink:

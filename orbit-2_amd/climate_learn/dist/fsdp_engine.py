@@ -14,7 +14,7 @@ A unit (one per Block, one for the head Sequential) exists in full only while it
 buffer of a small pool right before its forward (`_ops.unit_enter`) and again right before its backward
 (`_UnitBackwardGate`), on the communication stream and ONE UNIT AHEAD of the compute stream (the next unit in the recorded
 execution order is prefetched while the current one computes; the reference sets forward_prefetch=True); the buffer goes
-back to the pool when the unit's kernels have been queued.  The backward kernels write the unit's weight gradients into a
+back to the pool when the unit's forward (or backward: a second gate on the unit's input) has returned.  The backward kernels write the unit's weight gradients into a
 pooled gradient buffer; when the last one is in, the buffer is REDUCE-SCATTERED over the shard group into `gchunk16` (and, for
 HYBRID_SHARD, the chunk is all-reduced over the replica group), overlapping the rest of backward.  AdamW then runs on the
 chunks only.  The root unit (embeddings, final norm: used at both ends of the step) and the fp32-compute parameters
@@ -321,6 +321,10 @@ class HipFullyShardedDataParallel(nn.Module):
         if prv is not None:
             self._issue_gather(prv)
 
+    def post_backward(self, mod):
+        """the unit's backward has returned (gate on the unit's input): its gathered parameters go back to the pool"""
+        self._release(mod._o2_unit)
+
     # ---- gradient life cycle -----------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
         self.g32.zero_()
@@ -394,13 +398,12 @@ class HipFullyShardedDataParallel(nn.Module):
             u.handle = self._reduce_views(u)
             for h in u.handle:
                 h.wait()
-        if u.sharded:                                   # both pooled buffers go back; the unit's kernels are all queued
-            g = u.gbuf
-            for p, _, _ in u.members:
+        if u.sharded:                                   # the gradient buffer goes back to the pool (its next user waits for
+            g = u.gbuf                                  # the reduce-scatter's event); the gathered parameters stay until
+            for p, _, _ in u.members:                   # post_backward: input gradients of the unit may still be due
                 p._o2g = None
             u.gbuf = None
             self._gfree.append(g)
-            self._release(u)
 
     def finish_grad_sync(self):
         for u in self.units:
@@ -414,6 +417,8 @@ class HipFullyShardedDataParallel(nn.Module):
                 for h in u.handle:
                     h.wait()
                 u.handle = None
+        for u in self.sharded_units:                    # a unit whose input needed no gradient never saw post_backward
+            self._release(u)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 

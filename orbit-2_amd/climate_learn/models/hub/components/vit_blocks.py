@@ -63,7 +63,7 @@ class Block(nn.Module):
             "tp_group": self.tensor_par_group,
         }
         a, m = self.attn, self.mlp
-        _ops.unit_enter(self)          # parameter-sharding engine: gather this Block's weights (no-op otherwise)
+        x = _ops.unit_enter(self, x)   # parameter-sharding engine: gather this Block's weights (no-op otherwise)
         y = _ops.BlockFn.apply(x, cfg, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
                                a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight,
                                m.fc1.bias, m.fc2.weight, m.fc2.bias)

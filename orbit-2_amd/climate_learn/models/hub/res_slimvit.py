@@ -199,7 +199,7 @@ class Res_Slim_ViT(nn.Module):
         for m in self.head:
             if isinstance(m, HipLinear):
                 prm += [m.weight, m.bias]
-        _ops.unit_enter(self.head)
+        t = _ops.unit_enter(self.head, t)
         t = _ops.unit_exit(self.head, _ops.ChainFn.apply(t, {"ln": True}, *prm))
         img = self.unpatchify(t, scaling=self.superres_mag, out_channels=self.out_channels)
         co = self.conv_out

@@ -335,7 +335,7 @@ def _worker_fsdp(rank, world, port, q):
             pass
         for uname in ("blocks.0", "blocks.1", "head"):
             mod = m_fs.get_submodule(uname)
-            _ops.unit_enter(mod)
+            _ops.unit_enter(mod, torch.zeros(1))
             lowp = [(n, p) for n, p in mod.named_parameters() if getattr(p, "_o2_sharded", False)]
             assert len(lowp) == len(mod._o2_unit.members) > 0
             for n, p in lowp:
@@ -359,7 +359,9 @@ def _worker_fsdp(rank, world, port, q):
             for n, p in lowp:
                 fs.grad_ready(p)
                 rep.grad_ready(pr[uname + "." + n])
-            assert all(p._o2g is None and p._o2c is None for _, p in lowp)     # buffers released at launch
+            assert all(p._o2g is None and p._o2c is not None for _, p in lowp)   # gradients launched, weights still held
+            fs.post_backward(mod)
+            assert all(p._o2c is None for _, p in lowp)                          # ... until the unit's backward returns
         for n, p in pf.items():                      # the resident rest: root unit + fp32-compute parameters
             if getattr(p, "_o2_sharded", False) or not p.requires_grad:
                 continue
@@ -390,7 +392,7 @@ def _worker_fsdp(rank, world, port, q):
                 sg["p16"].copy_(sg["p32"])
         fs.gather_params()
         mod = m_fs.blocks[0]
-        _ops.unit_enter(mod)
+        _ops.unit_enter(mod, torch.zeros(1))
         u = mod._o2_unit
         for n, p in mod.named_parameters():          # every element moved by 1 + (the rank that owns its chunk)
             if not getattr(p, "_o2_sharded", False):
