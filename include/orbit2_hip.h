@@ -104,6 +104,12 @@ int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, cons
 /* dym = dy * dropmask * rowscale (backward of the dropout/DropPath epilogue); dym may alias dy */
 int orbit2_dropout_bwd(const void* dy, void* dym, int M, int N, float drop_p, uint64_t seed, const float* rowscale,
                        int rows_per_scale, void* stream);
+/* the same, fused with colsum_out[N] = beta*colsum_out + sum_m dym[m][n] (the bias gradient of the Linear whose output
+ * gradient dym is: reference autograd of attention.py:40,80-82 / mlp.py:54,66-68): dym is not re-read from HBM; result
+ * bit-identical to orbit2_dropout_bwd + orbit2_colsum.  ws: fp32 >= orbit2_colsum_ws_floats(M, N) */
+int orbit2_dropout_bwd_colsum(const void* dy, void* dym, int M, int N, float drop_p, uint64_t seed, const float* rowscale,
+                              int rows_per_scale, void* colsum_out, int out_fp32, float beta, float* ws, int ws_floats,
+                              void* stream);
 /* y = residual + rowscale[m/rows_per_scale] * dropout(x + addend[m % res_mod]) (bf16; every term optional): the part of
  * the GEMM epilogue that has to wait for the all-reduce of tensor-parallel partial products (row-parallel proj / fc2,
  * reference attention.py:81-85, mlp.py:66-71).  Same mask hash as the epilogue; y may alias x. */

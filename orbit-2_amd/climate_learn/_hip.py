@@ -268,6 +268,18 @@ def dropout_bwd(dy, M, N, drop_p, seed, rowscale=None, rows_per_scale=0, out=Non
     return out
 
 
+def dropout_bwd_colsum(dy, M, N, drop_p, seed, rowscale, rows_per_scale, colsum_out, beta=0.0):
+    """dym = dy * dropmask * rowscale and colsum_out[n] (+)= sum_m dym[m][n] in one pass"""
+    _dev(dy, BF, "dy")
+    out = torch.empty_like(dy)
+    n = lib().orbit2_colsum_ws_floats(M, N)
+    ws = torch.empty(n, dtype=F32, device=dy.device)
+    _chk(lib().orbit2_dropout_bwd_colsum(_p(dy), _p(out), M, N, C.c_float(drop_p), C.c_uint64(seed), _p(rowscale),
+                                         rows_per_scale, _p(colsum_out), int(colsum_out.dtype == F32), C.c_float(beta), _p(ws),
+                                         n, _stream()), "orbit2_dropout_bwd_colsum")
+    return out
+
+
 def post_reduce(x, M, N, addend=None, res_mod=0, residual=None, drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0,
                 out=None):
     """y = residual + rowscale * dropout(x + addend[m % res_mod]); in place on x unless `out` is given"""

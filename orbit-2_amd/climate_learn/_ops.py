@@ -216,6 +216,16 @@ def _drop_bwd(dy, M, N, p, seed, rowscale, rps):
     return dy
 
 
+def _drop_bwd_bias(dy, M, N, p, seed, rowscale, rps, b):
+    """dropout / DropPath backward of a Linear's output gradient together with that Linear's bias gradient (column sums of
+    the result) in ONE pass over dy; returns (dym, what backward must return for b, bias handled?)"""
+    if b is None or not (p > 0.0 or rowscale is not None) or N % 8:
+        return _drop_bwd(dy, M, N, p, seed, rowscale, rps), None, False
+    sb = _GradSink(b)
+    dym = _hip.dropout_bwd_colsum(dy, M, N, p, seed, rowscale, rps, sb.buf, beta=sb.beta)
+    return dym, sb.done(), True
+
+
 # ------------------------------------------------------------------------------------------------------
 # transformer block   (reference: components/vit_blocks.py:76-81, attention.py:43-87, mlp.py:57-73)
 # ------------------------------------------------------------------------------------------------------
@@ -302,8 +312,9 @@ class BlockFn(torch.autograd.Function):
             dx2 = dx2.contiguous().to(BF)
         # ---- MLP branch   (the four dW GEMMs are queued and issued as one grouped launch at the end)
         dws = _DwBatch()
-        dym2 = _drop_bwd(dx2, M, D, p_mlp, s2, dp2, L)
-        i2, gb2 = dws.add(dym2, hm, w2, b2, M, D, hid)
+        dym2, gb2, done2 = _drop_bwd_bias(dx2, M, D, p_mlp, s2, dp2, L, b2)      # fc2's bias gradient rides along
+        i2, gb2_ = dws.add(dym2, hm, w2, None if done2 else b2, M, D, hid)
+        gb2 = gb2 if done2 else gb2_
         dpre = _dx(dym2, w2, M, D, hid, drop_p=p_mlp, seed=s1, dgelu_pre=pre)
         del hm, pre, dym2
         i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D)
@@ -313,8 +324,9 @@ class BlockFn(torch.autograd.Function):
         dx1, gn2w, gn2b = _ln_bwd(dh2, x1, n2w, n2b, mean2, rstd2, dx2)
         del dh2, x1
         # ---- attention branch
-        dym1 = _drop_bwd(dx1, M, D, p_proj, sp, dp1, L)
-        ip, gbp = dws.add(dym1, o2d, wp, bp, M, D, Dl)
+        dym1, gbp, donep = _drop_bwd_bias(dx1, M, D, p_proj, sp, dp1, L, bp)     # proj's bias gradient rides along
+        ip, gbp_ = dws.add(dym1, o2d, wp, None if donep else bp, M, D, Dl)
+        gbp = gbp if donep else gbp_
         do = _dx(dym1, wp, M, D, Dl)
         del dym1
         dqkv = _hip.attn_bwd(qkv, o2d, do, lse, B, L, H, d, p_attn, sa)

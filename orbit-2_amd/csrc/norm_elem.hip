@@ -432,6 +432,60 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict
     }
   }
 }
+// dropout / DropPath backward FUSED with the column sums of its result (the bias gradient of the Linear whose output
+// gradient this is): the same [128 rows x 256 columns] blocks, thread mapping and summation order as colsum_part_kernel, so
+// the partials -- and the bias gradient -- are bit-identical to dropout_bwd + colsum, without re-reading dym from HBM.
+__global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dym,
+                                                                 int M, int N, unsigned thr, float dscale, uint64_t seed,
+                                                                 const float* __restrict__ rowscale, int rows_per_scale,
+                                                                 float* __restrict__ part) {
+  __shared__ float red[8][32][9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + tx) * 8;
+  const int r0 = blockIdx.y * CS_ROWS;
+  const int r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  const uint64_t sd = seed ^ o2_seed_salt;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const int64_t idx = (int64_t)r * N + c0;
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dy + idx), f);
+      if (thr) {
+        const uint32_t h0 = o2_hash64(sd, (uint64_t)idx >> 2), h1 = o2_hash64(sd, ((uint64_t)idx >> 2) + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[j] = (((h0 >> (8 * j)) & 0xffu) >= thr) ? f[j] * dscale : 0.f;
+          f[4 + j] = (((h1 >> (8 * j)) & 0xffu) >= thr) ? f[4 + j] * dscale : 0.f;
+        }
+      }
+      if (rowscale) {
+        const float sc = rowscale[r / rows_per_scale];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= sc;
+      }
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+      *reinterpret_cast<u32x4*>(dym + idx) = o;
+      unpack8(o, f);                                   // the sum is over the ROUNDED values (what colsum would read back)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx][j] = acc[j];
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][tx][j];
+      part[(size_t)blockIdx.y * N + c0 + j] = t;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int P, int N, void* out,
                                                             int out_fp32, float beta) {
   __shared__ float red[8][33];
@@ -712,6 +766,23 @@ extern "C" int orbit2_colsum(const void* x, int x_fp32, int M, int N, int ldx, v
   else hipLaunchKernelGGL(colsum_part_kernel<false>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
   O2_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, ws, P, N, out, out_fp32, beta);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_dropout_bwd_colsum(const void* dy, void* dym, int M, int N, float drop_p, uint64_t seed,
+                                         const float* rowscale, int rows_per_scale, void* colsum_out, int out_fp32, float beta,
+                                         float* ws, int ws_floats, void* stream) {
+  if (!dy || !dym || !colsum_out || !ws || M <= 0 || N <= 0 || (N & 7)) return O2_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f || (rowscale && rows_per_scale <= 0)) return O2_ERR_ARG;
+  const int P = (M + CS_ROWS - 1) / CS_ROWS;
+  if (ws_floats < P * N) return O2_ERR_ARG;
+  const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3((N + 255) / 256, P), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dym, M, N,
+                     thr, 256.0f / (256.0f - (float)thr), seed, rowscale, rows_per_scale, ws);
+  O2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, ws, P, N, colsum_out, out_fp32, beta);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

@@ -453,6 +453,24 @@ def test_colsum_batchsum(hip):
     assert nerr(o2, xb.sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,p,scaled,beta", [(300, 264, 0.1, True, 0.0), (1024, 512, 0.0, True, 1.0), (77, 64, 0.25, False, 0.0)])
+def test_dropout_bwd_colsum_equals_the_two_kernels(hip, M, N, p, scaled, beta):
+    """the fused pass (mask/DropPath backward + bias gradient) is bit-identical to dropout_bwd followed by colsum"""
+    g = torch.Generator().manual_seed(31)
+    dy = bf(torch.randn(M, N, generator=g)).cuda()
+    rps = 50
+    rs = (torch.rand((M + rps - 1) // rps, generator=g) * 2).cuda() if scaled else None
+    for dt in (torch.float32, torch.bfloat16):
+        base = torch.randn(N, generator=g).to(dt).cuda()
+        ref_dym = hip.dropout_bwd(dy, M, N, p, 1234, rs, rps)
+        ref_b = base.clone()
+        hip.colsum(ref_dym, M, N, N, ref_b, beta=beta)
+        got_b = base.clone()
+        got_dym = hip.dropout_bwd_colsum(dy, M, N, p, 1234, rs, rps, got_b, beta=beta)
+        assert torch.equal(got_dym, ref_dym)
+        assert torch.equal(got_b, ref_b)
+
+
 def test_bad_arguments_are_refused_not_run(hip):
     """the ABI validates shapes on the host and returns an error code (wrapped as HipBackendError); nothing is launched"""
     from climate_learn._hip import HipBackendError
