@@ -589,6 +589,236 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
     }
 }
 
+// =============================================================================================
+// backward, dK and dV of d = 128 in ONE pass (4 matrix products per query block instead of the split form's 5, one
+// softmax / dropout recomputation instead of two).  256 keys per workgroup, 8 waves, two waves per SIMD = 256 registers:
+//   * the wave's V rows stay in LDS (64 KB beside the 64 KB of Q / dO stages) and feed the dP MFMAs by ds_read_b128;
+//     K fragments (32), dK (64) and dV (64) accumulators are the only long-lived registers;
+//   * the tile loop is unrolled by two so the stage index is a compile-time constant: every LDS read is
+//     (one of 8 row-fragment / 8 transposed-fragment address registers) + immediate, no address arithmetic in the loop;
+//   * the dropout byte test is (word & bytemask) >= (thr << kbyte) on the quad-broadcast word (v_and_b32_dpp + v_cmp).
+// Results are bit-identical to the split passes (same per-element arithmetic and accumulation order).
+// =============================================================================================
+template <int V> struct IC { static constexpr int value = V; };
+
+// two floats -> packed bf16 pair as ONE v_cvt_pk_bf16_f32 (the shift-and-or form of pack_bf2 costs three more instructions)
+__device__ __forceinline__ unsigned cvt_pk_bf2(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+template <bool DROP, bool RAGGED>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* __restrict__ qkv,
+                                                                 const bf16_t* __restrict__ dout,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 bf16_t* __restrict__ dqkv, int L, int H, float scale,
+                                                                 unsigned thr, float dscale, uint64_t seed_arg) {
+  constexpr int D = 128, NW = 8;
+  using C = Cfg<D>;
+  constexpr int VOFF = 4 * C::TILE, SOFF = 8 * C::TILE;       // [2][Q|dO] | V rows of the workgroup | [2][lse2|delta|row hash]
+  __shared__ __attribute__((aligned(16))) char smem[SOFF + 2 * 3 * 64 * 4];
+  const uint64_t seed = seed_arg ^ o2_seed_salt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;
+  int tile_i, head, b;
+  attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
+  const int k0 = tile_i * (NW * 32) + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;
+  const size_t ostride = (size_t)H * D;
+  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
+  const bf16_t* kbase = qbase + (size_t)H * D;
+  const bf16_t* vbase = qbase + (size_t)2 * H * D;
+  const bf16_t* dobase = dout + (size_t)b * L * ostride + (size_t)head * D;
+  const int krow_raw = k0 + (lane & 31);
+  const bool k_ok = !RAGGED || krow_raw < L;
+  const int krow = k_ok ? krow_raw : L - 1;
+  const float sc_log2 = scale * 1.4426950408889634f;
+  float* sstat = reinterpret_cast<float*>(smem + SOFF);
+
+  bf16x8 kf[C::NDS];
+#pragma unroll
+  for (int ds = 0; ds < C::NDS; ++ds)
+    kf[ds] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
+#pragma unroll
+  for (int j = 0; j < NW / 2; ++j) {
+    int start = tile_i * (NW * 32) + j * 64, nv = L - start;
+    if (RAGGED && nv < 1) { start = L - 1; nv = 1; }      // a tile past the end reads the last row (its keys are discarded)
+    stage64<D, RAGGED, NW>(vbase + (size_t)start * tstride, tstride, smem + VOFF + j * C::TILE, wave, lane, nv);
+  }
+  f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+  for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  // ---- LDS addresses: row fragments (k-step ds of row lane&31) and transposed fragments (head-dim block db)
+  const char* rq[C::NDS];
+  {
+    const int r = lane & 31;
+#pragma unroll
+    for (int ds = 0; ds < C::NDS; ++ds) rq[ds] = smem + r * C::RB + (((ds * 2 + hq) ^ swz<D>(r)) << 4);
+  }
+  const int vwoff = VOFF + wave * 32 * C::RB;                 // this wave's 32 V rows
+  const char *t0[C::NDB], *t1[C::NDB];
+  {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = 4 * hq + q, row1 = row + 8;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) {
+      const int c = db * 4 + 2 * (g & 1) + (p >> 1);
+      t0[db] = smem + row * C::RB + ((c ^ swz<D>(row)) << 4) + 8 * (p & 1);
+      t1[db] = smem + row1 * C::RB + ((c ^ swz<D>(row1)) << 4) + 8 * (p & 1);
+    }
+  }
+  const float* st4 = sstat + 4 * hq;                                        // + (buf*3 + which)*64 + qb*32 + 8*g4
+  const uint32_t* sh1 = reinterpret_cast<const uint32_t*>(sstat) + 4 * hq + (lane & 3);
+
+  const size_t sbase = ((size_t)(b * H + head)) * L;
+  const uint64_t bh = (uint64_t)(b * H + head);
+  const uint32_t keyhash = DROP ? o2_attn_keyhash(seed, (uint32_t)(krow >> 2)) : 0u;   // this lane's key group
+  const uint32_t kbyte = 8 * (krow & 3);
+  const uint32_t bmask = 0xffu << kbyte, thrs = thr << kbyte;
+  const int nt = (L + 63) / 64;
+  const int nt2 = RAGGED ? ((nt + 1) & ~1) : nt;          // whole pairs of tiles (a tile past the end contributes nothing)
+  auto stage_stats = [&](int t, int buf) {
+    if (tid < 128) {
+      const int which = tid >> 6, i = tid & 63;
+      float v;
+      if (!RAGGED || t * 64 + i < L)
+        v = which ? (DROP ? delta[sbase + t * 64 + i] / dscale : delta[sbase + t * 64 + i])
+                  : lse[sbase + t * 64 + i] * 1.4426950408889634f;
+      else
+        v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
+      sstat[(buf * 3 + which) * 64 + i] = v;
+    } else if (DROP && tid < 192) {   // dropout: hashes of the tile's 64 query rows
+      const int i = tid & 63;
+      reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
+    }
+  };
+  auto stage_tile = [&](int t, int buf) {
+    int start = t * 64, nv = L - start;
+    if (RAGGED && nv < 1) { start = 0; nv = 64; }          // tile past the end: any valid rows (its statistics zero it)
+    stage64<D, RAGGED, NW>(qbase + (size_t)start * tstride, tstride, smem + buf * 2 * C::TILE, wave, lane, nv);
+    stage64<D, RAGGED, NW>(dobase + (size_t)start * ostride, ostride, smem + buf * 2 * C::TILE + C::TILE, wave, lane, nv);
+    stage_stats(t, buf);
+  };
+  stage_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto body = [&](auto CURTAG, int t) {
+    constexpr int CUR = decltype(CURTAG)::value;
+    constexpr int QO = CUR * 2 * C::TILE, DOO = QO + C::TILE;
+    if (t + 1 < nt2) stage_tile(t + 1, CUR ^ 1);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      // S[q x key] = Q . K^T, dP[q x key] = dO . V^T  (rows = queries in registers, column = key on the lane)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      int vw = vwoff;
+      asm volatile("" : "+s"(vw));          // keep the 8 V addresses out of registers: one v_add per read instead
+      // one k-step of operands in flight (12 registers), pinned: hipcc otherwise prefetches all 24 fragments (96 registers)
+      bf16x8 qf = *reinterpret_cast<const bf16x8*>(rq[0] + QO + qb * 32 * C::RB);
+      bf16x8 dof = *reinterpret_cast<const bf16x8*>(rq[0] + DOO + qb * 32 * C::RB);
+      bf16x8 vf = *reinterpret_cast<const bf16x8*>(rq[0] + vw);
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds) {
+        bf16x8 qn = qf, don = dof, vn = vf;
+        if (ds + 1 < C::NDS) {
+          qn = *reinterpret_cast<const bf16x8*>(rq[ds + 1] + QO + qb * 32 * C::RB);
+          don = *reinterpret_cast<const bf16x8*>(rq[ds + 1] + DOO + qb * 32 * C::RB);
+          vn = *reinterpret_cast<const bf16x8*>(rq[ds + 1] + vw);
+        }
+        s = MFMA32(qf, kf[ds], s);
+        dp = MFMA32(dof, vf, dp);
+        __builtin_amdgcn_sched_barrier(0);
+        qf = qn; dof = don; vf = vn;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t hmine[4] = {0u, 0u, 0u, 0u};
+      if (DROP) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) hmine[g4] = o2_attn_mix(sh1[(CUR * 3 + 2) * 64 + qb * 32 + 8 * g4], keyhash);
+      }
+      u32x4 pfw[2], dsw[2];     // P after dropout (for dV) and dS (for dK) as the operands of k-steps ss = 0, 1
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 0) * 64 + qb * 32 + 8 * g4);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 1) * 64 + qb * 32 + 8 * g4);
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g4 + e;
+          const float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse4[e]);
+          float dpr = dp[r];
+          float pdr = p;
+          if (DROP) {
+            const bool keep = (quad_bcast(hmine[g4], e) & bmask) >= thrs;
+            dpr = keep ? dpr : 0.f;     // dscale is applied once, on the final dK / dV tiles
+            pdr = keep ? p : 0.f;
+            asm volatile("" : "+v"(pdr));   // select in fp32, then convert pairs (else: single converts + v_perm merges)
+          }
+          pv[e] = pdr;
+          dsv[e] = p * (dpr - dl4[e]);  // dS
+        }
+        pfw[g4 >> 1][2 * (g4 & 1)] = cvt_pk_bf2(pv[0], pv[1]);
+        pfw[g4 >> 1][2 * (g4 & 1) + 1] = cvt_pk_bf2(pv[2], pv[3]);
+        dsw[g4 >> 1][2 * (g4 & 1)] = cvt_pk_bf2(dsv[0], dsv[1]);
+        dsw[g4 >> 1][2 * (g4 & 1) + 1] = cvt_pk_bf2(dsv[2], dsv[3]);
+      }
+      const bf16x8 pf[2] = {__builtin_bit_cast(bf16x8, pfw[0]), __builtin_bit_cast(bf16x8, pfw[1])};
+      const bf16x8 dsf[2] = {__builtin_bit_cast(bf16x8, dsw[0]), __builtin_bit_cast(bf16x8, dsw[1])};
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        auto trd = [&](int j, int off) {     // j = ss*4 + db
+          const int ro = (qb * 32 + (j >> 2) * 16) * C::RB + off;
+          const bf16x4 lo = lds_tr4(t0[j & 3] + ro), hi = lds_tr4(t1[j & 3] + ro);
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 fd = trd(0, DOO), fq = trd(0, QO);
+#pragma unroll
+        for (int j = 0; j < 2 * C::NDB; ++j) {
+          bf16x8 fdn = fd, fqn = fq;
+          if (j + 1 < 2 * C::NDB) { fdn = trd(j + 1, DOO); fqn = trd(j + 1, QO); }
+          dv[j & 3] = MFMA32(fd, pf[j >> 2], dv[j & 3]);     // dV^T += dO^T . P
+          dk[j & 3] = MFMA32(fq, dsf[j >> 2], dk[j & 3]);    // dK^T += Q^T . dS
+          __builtin_amdgcn_sched_barrier(0);
+          fd = fdn; fq = fqn;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int t = 0; t < nt2; t += 2) {
+    body(IC<0>{}, t);
+    body(IC<1>{}, t + 1);
+  }
+  if (!k_ok) return;
+  bf16_t* dkrow = dqkv + ((size_t)b * L + krow) * tstride + (size_t)H * D + (size_t)head * D;
+  bf16_t* dvrow = dkrow + (size_t)H * D;
+  const float fk = DROP ? scale * dscale : scale, fv = DROP ? dscale : 1.0f;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dd = db * 32 + 8 * g4 + 4 * hq;
+      u32x2 w;
+      w[0] = pack_bf2(dk[db][4 * g4] * fk, dk[db][4 * g4 + 1] * fk);
+      w[1] = pack_bf2(dk[db][4 * g4 + 2] * fk, dk[db][4 * g4 + 3] * fk);
+      *reinterpret_cast<u32x2*>(dkrow + dd) = w;
+      w[0] = pack_bf2(dv[db][4 * g4] * fv, dv[db][4 * g4 + 1] * fv);
+      w[1] = pack_bf2(dv[db][4 * g4 + 2] * fv, dv[db][4 * g4 + 3] * fv);
+      *reinterpret_cast<u32x2*>(dvrow + dd) = w;
+    }
+}
+
 }  // namespace
 
 O2_DEFINE_SALT_OP(attn)
@@ -612,6 +842,11 @@ static int attn_waves(int L, int d) {
   if (d == 256 || L < 256) return 4;
   const char* e = getenv("ORBIT2_ATTN_WAVES");
   return (e && e[0] == '4') ? 4 : 8;
+}
+
+static bool attn_fused_dkv() {           // d = 128: dK and dV in one pass; $ORBIT2_ATTN_DKV=split keeps the two-pass form (A/B)
+  const char* e = getenv("ORBIT2_ATTN_DKV");
+  return !(e && e[0] == 's');
 }
 
 template <int DV, bool DR, bool RG, int NW>
@@ -661,6 +896,9 @@ static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, co
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
                        dscale, seed);
+  } else if (DV == 128 && NW == 8 && attn_fused_dkv()) {   // one pass, V rows in LDS
+    hipLaunchKernelGGL((attn_bwd_dkv128_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
+                       seed);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 1, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
                        dscale, seed);
