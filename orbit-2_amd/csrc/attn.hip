@@ -54,12 +54,20 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {
 // dropout on a 32x32 tile whose lane-local axis (registers) runs along KEYS: registers 4t..4t+3 are keys
 // kbase + 8t + 4h + {0..3} of query row qrow -> one hash per 4 registers.
 // kh4[t] = key-group hash of keys kbase + 8t + 4h + {0..3} (from the tile's LDS table, see stage_keyhash)
+// PIN (forward, where the masked values are converted to bf16 next): the select stays in fp32 behind an opaque asm --
+// hipcc otherwise converts each value alone, selects, and merges pairs by v_perm (+3.6 % on the d = 128 forward); in the
+// dQ kernel the masked values feed fp32 arithmetic and the pin costs 2 %.
+template <bool PIN>
 __device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint32_t rowhash, const u32x4& kh4, unsigned thr) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint32_t hh = o2_attn_mix(rowhash, kh4[t]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) p[4 * t + e] = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+      float v = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : 0.f;
+      if (PIN) asm("" : "+v"(v));
+      p[4 * t + e] = v;
+    }
   }
 }
 
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
     if (DROP) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
-        drop_keys_in_regs(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
+        drop_keys_in_regs<true>(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
     }
     O2_SEG(tSM)
     // O^T[db] += V^T . P^T
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
         s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s);
         dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], dp);
       }
-      if (DROP) drop_keys_in_regs(dp, rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
+      if (DROP) drop_keys_in_regs<false>(dp, rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
       const bool tail = RAGGED && (t == nt - 1) && (L & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -599,8 +607,6 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
 //   * the dropout byte test is (word & bytemask) >= (thr << kbyte) on the quad-broadcast word (v_and_b32_dpp + v_cmp).
 // Results are bit-identical to the split passes (same per-element arithmetic and accumulation order).
 // =============================================================================================
-template <int V> struct IC { static constexpr int value = V; };
-
 // two floats -> packed bf16 pair as ONE v_cvt_pk_bf16_f32 (the shift-and-or form of pack_bf2 costs three more instructions)
 __device__ __forceinline__ unsigned cvt_pk_bf2(float lo, float hi) {
   typedef float f32x2_t __attribute__((ext_vector_type(2)));

@@ -67,4 +67,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rbase, int db, i
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+template <int V> struct IC { static constexpr int value = V; };   // compile-time tag for generic lambdas
+
 }  // namespace
