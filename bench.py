@@ -40,6 +40,7 @@ MODELS = {  # configs/interm_*.yaml of the reference
     "interm_10b": dict(embed_dim=8192, depth=11, num_heads=32),
 }
 PEAK_BF16 = 2.5e15   # dense MFMA peak, MI355X_MICROARCH.md
+MALL_JSON = "r02_mall_latency.json"  # Infinity-Cache share of that traffic (TCC_EA0_RDREQ_LEVEL pass of tools/mall_probe.py)
 TRAFFIC_JSON = "r02_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
 METRIC = "climate-grid samples/sec/node (fwd+bwd), interm_1b ERA5 1.4°→0.25°, 1/2/4/8 GPUs"
 
@@ -422,6 +423,18 @@ def main():
                 traffic = tj["gemm"]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        split = None       # Infinity-Cache hits vs HBM reads inside that counter traffic (tools/mall_probe.py: mean L2-miss latency)
+        try:
+            mj = json.load(open(os.path.join(ROOT, "profiles", MALL_JSON)))
+            share = {k: v["infinity_cache_hit_share_est"] for k, v in mj.items() if isinstance(v, dict) and "gemm" in k
+                     and "infinity_cache_hit_share_est" in v}
+            if share and traffic is not None:
+                lo = min(share.values())
+                split = {"infinity_cache_hit_share_of_reads": share, "hbm_bytes_per_launch_upper_estimate": traffic * (1.0 - lo),
+                         "method": "mean L2-miss latency (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ) interpolated between an HBM-stream and "
+                                   "an Infinity-Cache-stream calibration, profiles/" + MALL_JSON}
+        except Exception:
+            split = None
         ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["launches"] else 0.0
         out = {
             "metric": METRIC, "value": sps, "unit": "samples/s", "n_gpus": world, "rccl_ranks": ranks_met,
@@ -440,7 +453,7 @@ def main():
                        "hipgraph": bool(a.graph),
                        "loss": "perceptual" if a.daymet else "bayesian_tv", "in_vars": V},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic,
+                         "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_split": split,
                          "algorithmic_bytes_per_launch": gm.get("bytes", None),
                          "kernel": "orbit2_gemm_bf16 / orbit2_gemm_bf16_grouped (csrc/gemm.hip, hand-written MFMA kernels): "
                                    "EVERY GEMM of the step -- forward, input gradients, weight gradients -- all launches "

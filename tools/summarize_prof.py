@@ -50,7 +50,7 @@ def traffic(fetch_csv, write_csv, out):
     fam = {"gemm": ("gemm256t_kernel", "gemm256t_grouped_kernel", "gemm128_kernel", "gemm128_grouped_kernel"),
            "gemm_8phase_single": ("gemm256t_kernel",), "gemm_8phase_grouped_dw": ("gemm256t_grouped_kernel",),
            "attn_fwd": ("attn_fwd_kernel",),
-           "attn_bwd_dq": ("attn_bwd_dq_kernel",), "attn_bwd_dkv": ("attn_bwd_dkv_kernel",)}
+           "attn_bwd_dq": ("attn_bwd_dq_kernel",), "attn_bwd_dkv": ("attn_bwd_dkv_kernel", "attn_bwd_dkv128_kernel")}
     acc = {k: {"FETCH_SIZE": [], "WRITE_SIZE": []} for k in fam}
     for path in (fetch_csv, write_csv):
         for r in csv.DictReader(open(path)):
@@ -71,6 +71,48 @@ def traffic(fetch_csv, write_csv, out):
                     "is L2-miss traffic (Infinity-Cache hits included)")
     res["_config"] = {"model": "interm_1b", "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 8, "grid": "128x256"}
     json.dump(res, open(out, "w"), indent=1)
+
+
+def mall(path, out):
+    """TCC_EA0_RDREQ / _LEVEL / _DRAM pass of tools/mall_probe.py -> mean L2-miss latency per kernel and the Infinity-Cache
+    hit share interpolated between the two calibration streams (hbm = bf16 reduce of 4 GB, mall = fp32 reduce of 96 MB)."""
+    import json
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.OrderedDict()
+    for r in rows:
+        n = r["Kernel_Name"]
+        if "reduce_kernel" in n:
+            k = "calibration_hbm_stream(4GB bf16 sum)" if "BFloat16" in n else "calibration_mall_stream(96MB fp32 sum)"
+        else:
+            k = short(n)
+            if not any(s in k for s in ("gemm", "attn_fwd", "attn_bwd")):
+                continue
+        agg.setdefault(k, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = collections.OrderedDict()
+    for k, d in agg.items():
+        req, lvl = d.get("TCC_EA0_RDREQ_sum", []), d.get("TCC_EA0_RDREQ_LEVEL_sum", [])
+        if k.startswith("calibration_mall") and len(req) > 4:      # the first pass is the cold one
+            req, lvl = req[2:], lvl[2:]
+        dram = d.get("TCC_EA0_RDREQ_DRAM_sum", [])
+        if not req or sum(req) == 0:
+            continue
+        res[k] = {"dispatches": len(req), "rdreq_per_dispatch": sum(req) / len(req),
+                  "mean_l2_miss_latency_cycles": sum(lvl) / sum(req),
+                  "rdreq_dram_share": (sum(dram) / sum(d.get("TCC_EA0_RDREQ_sum", [1]))) if dram else None}
+    ch = [v for k, v in res.items() if k.startswith("calibration_hbm")]
+    cm = [v for k, v in res.items() if k.startswith("calibration_mall")]
+    if ch and cm:
+        lh, lm = ch[0]["mean_l2_miss_latency_cycles"], cm[0]["mean_l2_miss_latency_cycles"]
+        for k, v in res.items():
+            if not k.startswith("calibration"):
+                f = (lh - v["mean_l2_miss_latency_cycles"]) / (lh - lm) if lh != lm else float("nan")
+                v["infinity_cache_hit_share_est"] = max(0.0, min(1.0, f))
+    res["_note"] = ("TCC_EA0_RDREQ_LEVEL_sum / TCC_EA0_RDREQ_sum = mean latency of an L2 miss (TCC cycles); hit share = linear "
+                    "interpolation between the HBM-stream and the Infinity-Cache-stream calibrations run in the same process; "
+                    "TCC_EA0_RDREQ_DRAM counts requests routed to local memory (vs GMI / IO), not Infinity-Cache misses")
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res.items():
+        print(k, v)
 
 
 def mfma(path, out):
@@ -103,6 +145,9 @@ if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "mfma":
         mfma(sys.argv[2], sys.argv[3])
+        sys.exit(0)
+    if mode == "mall":
+        mall(sys.argv[2], sys.argv[3])
         sys.exit(0)
     if mode == "traffic":
         traffic(*sys.argv[2:5])
