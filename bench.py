@@ -430,9 +430,12 @@ def main():
                      and "infinity_cache_hit_share_est" in v}
             if share and traffic is not None:
                 lo = min(share.values())
-                split = {"infinity_cache_hit_share_of_reads": share, "hbm_bytes_per_launch_upper_estimate": traffic * (1.0 - lo),
+                alg = gm.get("bytes", None) or 0.0     # compulsory bytes: every operand read once, the result written once
+                split = {"infinity_cache_hit_share_of_reads": share,
+                         "hbm_bytes_per_launch_estimate": max(alg, traffic * (1.0 - lo)),
                          "method": "mean L2-miss latency (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ) interpolated between an HBM-stream and "
-                                   "an Infinity-Cache-stream calibration, profiles/" + MALL_JSON}
+                                   "an Infinity-Cache-stream calibration, profiles/" + MALL_JSON + "; the estimate is floored at the "
+                                   "algorithmic bytes (a share that clips to 1.0 means the re-reads never leave the die)"}
         except Exception:
             split = None
         ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["launches"] else 0.0
