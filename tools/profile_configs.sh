@@ -1,11 +1,12 @@
 set -e
-# usage (on the GPU box): bash tools/profile_configs.sh  -- rocprofv3 kernel statistics of the other BASELINE configs
+# usage (on the GPU box): bash tools/profile_configs.sh [tag]  -- rocprofv3 kernel statistics of the other BASELINE configs
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() {  # name, bench args...
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -o $name -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/bench_$name.json 2> $R/gpurun_out/bench_$name.err
-  python3 $R/tools/summarize_prof.py stats $R/gpurun_out/prof_$name/${name}_kernel_stats.csv $R/gpurun_out/r01_${name}_kernel_stats.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -o $name -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_bench_$name.json 2> $R/gpurun_out/bench_$name.err
+  python3 $R/tools/summarize_prof.py stats $R/gpurun_out/prof_$name/${name}_kernel_stats.csv $R/gpurun_out/${TAG}_${name}_kernel_stats.txt
   echo $name-done
 }
 run interm10b_b1_recompute --model interm_10b --batch 1 --recompute --steps 3 --warmup 1
