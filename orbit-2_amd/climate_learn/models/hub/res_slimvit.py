@@ -152,13 +152,22 @@ class Res_Slim_ViT(nn.Module):
         if grp is not None:    # replicated inputs of a head-split attention: their gradients are partial per rank
             vq = _tp.IdentityFwdAllReduceBwd.apply(vq, grp)            # (attention.py:134-137)
         qv = _ops.sgemm(vq, wq, tb=True)                                         # [1, Dl] = var_query Wq^T
-        qblk = torch.block_diag(*qv.view(H, 1, dh).unbind(0))                    # [H, Dl], head-block structure
+        ekey = ("eye", H, str(wq.device))
+        eye = self._idx_cache.get(ekey)
+        if eye is None:
+            eye = self._idx_cache[ekey] = torch.eye(H, dtype=torch.float32, device=wq.device).unsqueeze(-1)
+        qblk = (eye * qv.view(1, H, dh)).view(H, Dl)                             # [H, Dl], head-block structure (one launch)
         u = _ops.sgemm(qblk, wkv[:Dl]) * (dh ** -0.5)                            # [H, D] = scale * q_h^T Wk_h
-        rows = []
-        for v in ids:
-            te = self.token_embeds[v].proj
-            rows.append(torch.cat([te.weight.view(D, 4).t(), (te.bias + self.var_embed[0, v]).view(1, D)], 0))
-        cmat = torch.stack(rows).view(len(ids) * 5, D)                           # [(v,c), D]
+        # rows (v, c): the 4 patch weights of variable v and its bias + variable embedding -- built for all variables at once
+        # (five launches forward; the per-variable form was ~12 tiny launches per variable and step, 10 % of an interm_117m step)
+        tes = [self.token_embeds[v].proj for v in ids]
+        key = (tuple(ids), str(wq.device))
+        ids_t = self._idx_cache.get(key)
+        if ids_t is None:
+            ids_t = self._idx_cache[key] = torch.tensor(list(ids), dtype=torch.long, device=wq.device)
+        w4 = torch.stack([te.weight.view(D, 4) for te in tes]).transpose(1, 2)    # [V, 4, D]
+        b1 = torch.stack([te.bias for te in tes]) + self.var_embed[0].index_select(0, ids_t)        # [V, D]
+        cmat = torch.cat([w4, b1.unsqueeze(1)], 1).reshape(len(ids) * 5, D)      # [(v,c), D]
         if grp is not None:
             cmat = _tp.IdentityFwdAllReduceBwd.apply(cmat, grp)
         stab = _ops.sgemm(u, cmat, tb=True).view(H, len(ids), 5)
