@@ -198,14 +198,30 @@ def cpu_baseline(model_name, V, C):
         tt = _oracle_steps(model_name, ERA5_VARS, OUT_VARS, 1, grid, "bayesian_tv", 1, 2, "interm_1b 16x32 tile")
         dt = sum(tt) / len(tt)
         m = MODELS[model_name]
-        f_tile = O.forward_flops(grid[0] * grid[1] // 4, V, m["embed_dim"], m["depth"], 4, C, grid[0], grid[1], m["num_heads"])
-        f_full = O.forward_flops(8192, V, m["embed_dim"], m["depth"], 4, C, 128, 256, m["num_heads"])
+        f_tile = forward_flops(grid[0] * grid[1] // 4, V, m["embed_dim"], m["depth"], 4, C, grid[0], grid[1], m["num_heads"])
+        f_full = forward_flops(8192, V, m["embed_dim"], m["depth"], 4, C, 128, 256, m["num_heads"])
         out["interm_1b_tile_estimate"] = {
             "value": (1.0 / dt) * f_tile / f_full, "unit": "samples/s",
             "sample": "ESTIMATE: interm_1b on one 16x32 tile (L=128), batch 1, 2 timed steps of %.2f s, extrapolated to the "
                       "128x256 grid by the dense-FLOP ratio %.5f (attention is ~0 %% of the tile's FLOPs and 22 %% of "
                       "the full grid's, so this flatters the CPU)" % (dt, f_tile / f_full)}
     return out
+
+
+def forward_flops(L, V, D, depth, dd, C, h, w, heads, p=2, s=4, cr=4, r=4, folded_varagg=False):
+    """Forward FLOPs per sample, SURVEY.md 8(d) (multiply-add = 2; softmax / LN / GELU not counted); model FLOPs = 3x this.
+    folded_varagg=True: what this build executes for the variable aggregation (5 MACs per (token, variable, channel) + the
+    scores + the projection) instead of the reference's dense kv GEMM.  tests/test_oracle_golden.py pins it to the survey's
+    probe values and to the oracle's copy."""
+    pe = 2 * L * V * p * p * D
+    if folded_varagg:
+        va = 2 * L * V * D * 5 + 2 * L * V * heads * 5 + 2 * L * D * D
+    else:
+        va = 2 * L * V * D * 2 * D + 2 * (2 * L * D * D) + 4 * L * V * D + pe
+    blk = depth * (2 * L * D * 3 * D + 4 * L * L * D + 2 * L * D * D + 4 * L * D * r * D)
+    head = dd * 2 * L * D * D + 2 * L * D * C * (p * s) ** 2
+    convs = 2 * h * w * (C + 4) * (cr * s * s) * 9 + 2 * (16 * h * w) * cr * C * 9 + 2 * (16 * h * w) * C * C * 9
+    return va + blk + head + convs
 
 
 def self_launch(a):
@@ -284,7 +300,6 @@ def main():
     from climate_learn.models.hub import Res_Slim_ViT
     from climate_learn.models.hub.components.vit_blocks import Block
     from climate_learn.trainer import training_step
-    from oracle.orbit2_oracle import forward_flops   # FLOP model only (no compute)
 
     m = MODELS[a.model]
     h, w = (int(v) for v in a.grid.split("x"))

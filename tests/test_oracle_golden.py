@@ -201,6 +201,18 @@ def test_flop_model_matches_survey():
     assert abs(f / 1.679e11 - 1) < 2e-3
 
 
+def test_bench_flop_model_is_the_oracles():
+    """bench.py carries its own copy of the SURVEY 8(d) formula (the product-side measurement does not import oracle/)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("o2_bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for args in [(8192, 23, 3072, 8, 4, 3, 128, 256, 24), (512, 23, 1024, 8, 4, 3, 32, 64, 16), (512, 5, 256, 6, 1, 1, 32, 64, 4),
+                 (8192, 23, 8192, 11, 4, 3, 128, 256, 32)]:
+        for fold in (False, True):
+            assert bench.forward_flops(*args, folded_varagg=fold) == O.forward_flops(*args, folded_varagg=fold)
+
+
 def test_eval_metrics_match_reference(golden_dir):
     """rmse / lat-weighted rmse / pearson / mean_bias against the reference's own functions (make_golden_eval.py)"""
     z = np.load(os.path.join(golden_dir, "eval_metrics.npz"))
