@@ -225,7 +225,7 @@ def _attn_ref(qkv, B, L, H, d, mask=None, sc=1.0):
 
 
 @pytest.mark.parametrize("d,H,L,B", [(64, 2, 128, 2), (128, 2, 256, 1), (64, 4, 512, 1), (128, 3, 384, 2), (256, 2, 128, 1), (256, 1, 256, 2),
-                                       (128, 2, 200, 1), (64, 2, 578, 2), (128, 1, 70, 2), (256, 1, 161, 1)])
+                                       (128, 2, 200, 1), (64, 2, 578, 2), (128, 1, 70, 2), (256, 1, 161, 1), (128, 2, 300, 1)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attention_fwd_bwd(hip, d, H, L, B, p):
     g = torch.Generator().manual_seed(d + L)
@@ -249,6 +249,27 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
     dv = dqkv.view(B, L, 3, H * d)
     for i, nm in enumerate("qkv"):
         assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
+
+
+@pytest.mark.parametrize("L", [256, 300, 1024 + 96, 2048])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_dkv_one_pass_equals_two_passes(hip, L, p):
+    """d = 128, >= 256 tokens: dK and dV come from ONE pass (V rows in LDS, csrc/attn.hip attn_bwd_dkv128_kernel); the
+    two-pass kernels stay selectable ($ORBIT2_ATTN_DKV=split) and must give the same bits -- odd tile counts (L = 300:
+    5 tiles, the pair loop's sixth is past the end) and ragged tails included"""
+    import os
+    B, H, d = 2, 3, 128
+    g = torch.Generator().manual_seed(L)
+    qkv = bf(torch.randn(B, L, 3 * H * d, generator=g) * 0.7).cuda()
+    do = bf(torch.randn(B, L, H * d, generator=g)).cuda()
+    out, lse = hip.attn_fwd(qkv, B, L, H, d, p, 4242)
+    one = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, 4242)
+    os.environ["ORBIT2_ATTN_DKV"] = "split"
+    try:
+        two = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, 4242)
+    finally:
+        os.environ.pop("ORBIT2_ATTN_DKV", None)
+    assert torch.equal(one, two)
 
 
 def test_attention_forced_late_rescale(hip):
