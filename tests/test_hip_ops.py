@@ -251,7 +251,7 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
         assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
 
 
-@pytest.mark.parametrize("L", [256, 300, 1024 + 96, 2048])
+@pytest.mark.parametrize("L", [256, 257, 300, 320, 511, 513, 1024 + 96, 2048])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attention_dkv_one_pass_equals_two_passes(hip, L, p):
     """d = 128, >= 256 tokens: dK and dV come from ONE pass (V rows in LDS, csrc/attn.hip attn_bwd_dkv128_kernel); the
