@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ORBIT2_ABI_VERSION 1
+#define ORBIT2_ABI_VERSION 2
 int orbit2_abi_version(void);
 
 /* ---- bf16 MFMA GEMM with fused epilogue ------------------------------------------------
@@ -28,7 +28,7 @@ int orbit2_abi_version(void);
  * Replaces every nn.Linear on the path: attention.py:36,40,50,81; mlp.py:50,54,63,67;
  * res_slimvit.py:115-120,326 (head); var_agg.proj attention.py:129,177 -- forward (a_kc=b_kc=1),
  * input-gradient (a_kc=1,b_kc=0) and weight-gradient (a_kc=b_kc=0) forms.
- * Epilogue order: +bias -> save_pre -> GELU -> [+residual if res_first] -> dropout ->
+ * Epilogue order: +bias -> *colscale (columns n < colscale_n) -> save_pre -> GELU -> [+residual if res_first] -> dropout ->
  *   *gelu'(dgelu_pre) -> *rowscale[m / rows_per_scale] -> [+residual] -> C = beta*C + v.
  * Requirements: N % 8 == 0; M % 8 == 0 unless a_kc (any M then); K % 8 == 0 if an operand is K-contiguous, any K when
  * both are K-strided (the weight-gradient form: K = tokens); lda/ldb/ldc % 8 == 0, 16-byte aligned bases. */
@@ -50,6 +50,8 @@ typedef struct {
   int out_fp32;            /* 0: C is bf16, 1: C is fp32 */
   float beta;              /* C = beta*C + result (gradient accumulation) */
   int tile_hint;           /* 0 = auto, 128 or 256 = force that kernel (tests / tuning; 256 needs K % 64 == 0) */
+  int colscale_n;          /* columns n < colscale_n (a multiple of 8; 0 = none) are multiplied by colscale in fp32 right after */
+  float colscale;          /*   the bias: the qkv Linear stores q * log2(e)/sqrt(d) (attention.py:50,54: q * scale), rounded ONCE */
 } orbit2_gemm_args;
 int orbit2_gemm_bf16(const orbit2_gemm_args* args, void* stream);
 
@@ -88,6 +90,21 @@ int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H,
 /* dqkv: bf16 [B, L, 3, H, d];  delta: fp32 workspace [B, H, L] */
 int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                     void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, void* stream);
+/* The same two entries with the kernel variant as an ARGUMENT (A/B timing and the bit-equality tests of the fused
+ * d = 128 dK+dV pass): flags = 0 is what orbit2_attn_fwd / _bwd run.  Nothing on the launch path reads the environment
+ * or any other process-global switch. */
+#define ORBIT2_ATTN_4WAVES 1     /* 4-wave / 128-row workgroups (round-1 geometry) instead of 8-wave / 256-row ones */
+#define ORBIT2_ATTN_SPLIT_DKV 2  /* d = 128: dK and dV as two passes instead of the fused one */
+/* The q third of qkv already holds q * log2(e)/sqrt(d) (written so by the qkv GEMM's colscale epilogue: ONE rounding to
+ * bf16, products with k exact, like the reference's fp32 scaling of q k^T).  Without the flag the kernels multiply their
+ * register-resident operand (q, or k in the dK/dV pass) by that factor themselves and round it to bf16 a second time
+ * (relative 2^-9 per element of that operand: harmless at ordinary score magnitudes, ~1e-2 of the output when scores reach
+ * tens of nats).  dqkv is in both cases the gradient with respect to the UNSCALED q, k, v. */
+#define ORBIT2_ATTN_Q_PRESCALED 4
+int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
+                       uint64_t seed, int flags, void* stream);
+int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                       void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, int flags, void* stream);
 
 /* ---- folded patch-embed + variable aggregation (res_slimvit.py:250-265, 205-230;
  *      patch_embed.py:44-52; attention.py:132-176) ---------------------------------------------

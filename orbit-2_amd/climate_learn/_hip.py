@@ -41,6 +41,8 @@ class GemmArgs(C.Structure):
         ("out_fp32", C.c_int),
         ("beta", C.c_float),
         ("tile_hint", C.c_int),
+        ("colscale_n", C.c_int),
+        ("colscale", C.c_float),
     ]
 
 
@@ -53,7 +55,7 @@ def lib():
                 "liborbit2_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        if _lib.orbit2_abi_version() != 1:
+        if _lib.orbit2_abi_version() != 2:
             raise HipBackendError("liborbit2_hip.so ABI version mismatch")
     return _lib
 
@@ -112,7 +114,7 @@ timer: Optional[KernelTimer] = None
 # ------------------------------------------------------------------------------------------------
 def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None,
                dgelu_pre=None, drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0,
-               res_first=False, beta=0.0, tile=0):
+               res_first=False, beta=0.0, tile=0, colscale=None):
     for t, nm in ((A, "A"), (B, "B")):
         _dev(t, BF, nm)
     if out.dtype not in (BF, F32) or not out.is_cuda:
@@ -132,6 +134,7 @@ def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=
     a.out_fp32 = int(out.dtype == F32)
     a.beta = float(beta)
     a.tile_hint = int(tile)
+    a.colscale_n, a.colscale = (0, 1.0) if colscale is None else (int(colscale[0]), float(colscale[1]))
     return 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0)
 
 
@@ -211,29 +214,32 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, beta_acc=0.0):
     return dx
 
 
-def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0):
+ATTN_4WAVES, ATTN_SPLIT_DKV, ATTN_Q_PRESCALED = 1, 2, 4      # include/orbit2_hip.h: kernel-variant flags of the *_ex attention entries (A/B, tests)
+
+
+def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0, flags=0):
     _dev(qkv, BF, "qkv")
     out = torch.empty(B, L, H * d, dtype=BF, device=qkv.device)
     lse = torch.empty(B, H, L, dtype=F32, device=qkv.device)
     if timer is not None:
         e0, e1 = timer.span("attn_fwd", 4.0 * B * H * L * L * d)
         e0.record()
-    _chk(lib().orbit2_attn_fwd(_p(qkv), _p(out), _p(lse), B, L, H, d, C.c_float(drop_p), C.c_uint64(seed), _stream()),
-         "orbit2_attn_fwd")
+    _chk(lib().orbit2_attn_fwd_ex(_p(qkv), _p(out), _p(lse), B, L, H, d, C.c_float(drop_p), C.c_uint64(seed), int(flags),
+                                  _stream()), "orbit2_attn_fwd_ex")
     if timer is not None:
         e1.record()
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, d, drop_p=0.0, seed=0):
+def attn_bwd(qkv, out, dout, lse, B, L, H, d, drop_p=0.0, seed=0, flags=0):
     _dev(qkv, BF, "qkv"); _dev(out, BF, "out"); _dev(dout, BF, "dout"); _dev(lse, F32, "lse")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, L, dtype=F32, device=qkv.device)
     if timer is not None:
         e0, e1 = timer.span("attn_bwd", 8.0 * B * H * L * L * d)     # algorithmic: 2x forward (recompute not credited)
         e0.record()
-    _chk(lib().orbit2_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, L, H, d,
-                               C.c_float(drop_p), C.c_uint64(seed), _stream()), "orbit2_attn_bwd")
+    _chk(lib().orbit2_attn_bwd_ex(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, L, H, d,
+                                  C.c_float(drop_p), C.c_uint64(seed), int(flags), _stream()), "orbit2_attn_bwd_ex")
     if timer is not None:
         e1.record()
     return dqkv

@@ -22,6 +22,8 @@ import torch
 from . import _hip
 from .dist import tp as _tp
 
+_Q_PRESCALE = 1.4426950408889634      # log2(e): q is stored as q * log2(e)/sqrt(d) (include/orbit2_hip.h, ORBIT2_ATTN_Q_PRESCALED)
+
 BF, F32 = torch.bfloat16, torch.float32
 
 
@@ -270,8 +272,10 @@ class BlockFn(torch.autograd.Function):
         sa, sp, s1, s2 = sds
         Dl = H * d                                  # = D on one rank, D / tensor_par_size under head-split
         h1, mean1, rstd1 = _hip.layernorm_fwd(x2d, cw(n1w), cw(n1b))
-        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * Dl, D)
-        o, lse = _hip.attn_fwd(qkv, B, L, H, d, p_attn, sa)
+        # the q third leaves the GEMM epilogue as q * log2(e)/sqrt(d) (fp32 product, ONE rounding to bf16): the attention
+        # kernels' scores are exp2 arguments with exact bf16 x bf16 products, as with the reference's fp32 scaling
+        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * Dl, D, colscale=(Dl, _Q_PRESCALE / math.sqrt(d)))
+        o, lse = _hip.attn_fwd(qkv, B, L, H, d, p_attn, sa, flags=_hip.ATTN_Q_PRESCALED)
         o2d = o.view(M, Dl)
         if grp is None:
             x1 = _linear_fwd(o2d, wp, bp, M, D, Dl, drop_p=p_proj, seed=sp, rowscale=dp1, rows_per_scale=L,
@@ -329,7 +333,8 @@ class BlockFn(torch.autograd.Function):
         gbp = gbp if donep else gbp_
         do = _dx(dym1, wp, M, D, Dl)
         del dym1
-        dqkv = _hip.attn_bwd(qkv, o2d, do, lse, B, L, H, d, p_attn, sa)
+        # (dqkv is the gradient with respect to the UNSCALED q, k, v: the qkv GEMM's backward needs no column scale)
+        dqkv = _hip.attn_bwd(qkv, o2d, do, lse, B, L, H, d, p_attn, sa, flags=_hip.ATTN_Q_PRESCALED)
         del do, o2d, qkv
         iq, gbqkv = dws.add(dqkv, h1, wqkv, bqkv, M, 3 * Dl, D)
         dh1 = _dx(dqkv, wqkv, M, 3 * Dl, D)

@@ -36,6 +36,22 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
   return r;
 }
 
+// two floats -> packed bf16 pair as ONE v_cvt_pk_bf16_f32 (the shift-and-or form of pack_bf2 costs three more instructions)
+__device__ __forceinline__ unsigned cvt_pk_bf2(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// bf16 fragment times a scalar, rounded to bf16 once (the softmax scale folded into an MFMA operand)
+__device__ __forceinline__ bf16x8 scale_frag(const bf16x8& x, float c) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)x[j]) * c);
+  return r;
+}
+
 template <int J>
 __device__ __forceinline__ uint32_t quad_bcast_c(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xf, 0xf, true);
@@ -58,13 +74,14 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {
 // hipcc otherwise converts each value alone, selects, and merges pairs by v_perm (+3.6 % on the d = 128 forward); in the
 // dQ kernel the masked values feed fp32 arithmetic and the pin costs 2 %.
 template <bool PIN>
-__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint32_t rowhash, const u32x4& kh4, unsigned thr) {
+__device__ __forceinline__ void drop_keys_in_regs(f32x16& p, uint32_t rowhash, const u32x4& kh4, unsigned thr,
+                                                  float dropped = 0.f) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint32_t hh = o2_attn_mix(rowhash, kh4[t]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float v = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : 0.f;
+      float v = (((hh >> (8 * e)) & 0xffu) >= thr) ? p[4 * t + e] : dropped;
       if (PIN) asm("" : "+v"(v));
       p[4 * t + e] = v;
     }
@@ -262,6 +279,238 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
 }
 
 // =============================================================================================
+// forward WITHOUT dropout (eval / inference, attn_drop = 0): lazy reference
+// =============================================================================================
+// Q enters the S MFMAs pre-multiplied by log2(e)/sqrt(d) and the accumulators START at -(reference of the row): the scores
+// leave the matrix pipe as exp2 arguments.  The reference is the row's maximum over the first tile and stays FIXED while no
+// probability relative to it leaves [0, 2^40]: P, O and l share it and fp32 / bf16 keep their relative precision at any scale,
+// so the result is exact, and a score element costs one exp2, one add and its share of the bf16 conversion (124 vector
+// instructions per 64-key tile against 200 in attn_fwd_kernel<.., DROP = false, ..>: +6 % at the interm_1b shape,
+// profiles/r03_attn_fwd_variants.txt).  The row sums are the guard: a wave in which one leaves the range continues in an
+// online-softmax loop.  With dropout the same formulation is 6-16 % SLOWER than attn_fwd_kernel in five variants (guard
+// placement, priority, pinned / free select, subtract instead of accumulator start): hipcc's schedule of that loop, not its
+// instruction count (243 against 306), decides -- the dropout forward stays as it was.
+template <int D, bool RAGGED, int NW>
+__global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ lse, int L, int H, float sc_log2,
+                                                          unsigned thr, float dscale, uint64_t seed_arg) {
+  constexpr bool DROP = false;                      // (the dropout forward is attn_fwd_kernel above)
+  const uint64_t seed = seed_arg ^ o2_seed_salt;
+  using C = Cfg<D>;
+  constexpr int KT = 1;      // 64-key tiles per stage and per workgroup barrier (2 was measured: no gain)
+  constexpr int STAGE = KT * 2 * C::TILE;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];        // [2 stages][KT][K | V]
+  __shared__ __attribute__((aligned(16))) uint32_t skh[2][KT * 16];    // [stage][tile] key-group hashes of the tile (dropout)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;  // MFMA half
+  int tile_i, head, b;
+  attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
+  const int q0 = tile_i * (NW * 32) + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;  // token stride in qkv
+  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
+  const bf16_t* kbase = qbase + (size_t)H * D;
+  const bf16_t* vbase = qbase + (size_t)2 * H * D;
+  const int qrow_raw = q0 + (lane & 31);
+  const bool q_ok = !RAGGED || qrow_raw < L;
+  const int qrow = q_ok ? qrow_raw : L - 1;   // ragged tail: compute on a valid row, never store it
+
+  // Q enters the S MFMAs pre-multiplied by log2(e)/sqrt(d) (rounded to bf16 once, here): the scores leave the matrix
+  // pipe in the exp2 domain, and with the accumulators STARTED at -m_run they are the exp2 arguments -- no multiply, no
+  // subtraction and (below) no row maximum per score element.
+  bf16x8 qf[C::NDS];
+#pragma unroll
+  for (int ds = 0; ds < C::NDS; ++ds)
+    qf[ds] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq), sc_log2);
+
+  f32x16 o[C::NDB];
+#pragma unroll
+  for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = 0.f, l_run = 0.f;
+  const uint32_t rowhash = DROP ? o2_attn_rowhash(seed, (uint64_t)(b * H + head) * L + (uint64_t)qrow) : 0u;
+
+  const int nt = (L + 63) / 64;
+  int cur = 0;
+  // stage the KT tiles of super-tile T into buffer `buf` (tiles past the end of the sequence are not staged, nor read)
+  auto stage_super = [&](int T, int buf) {
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const int tt = T * KT + j;
+      if (tt < nt) {
+        char* nk = smem + buf * STAGE + j * 2 * C::TILE;
+        stage64<D, RAGGED, NW>(kbase + (size_t)tt * 64 * tstride, tstride, nk, wave, lane, L - tt * 64);
+        stage64<D, RAGGED, NW>(vbase + (size_t)tt * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - tt * 64);
+        if (DROP) stage_keyhash(skh[buf] + j * 16, seed, tt, tid);
+      }
+    }
+  };
+  stage_super(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#ifdef O2_STAMP
+  unsigned tS = 0, tQK = 0, tSM = 0, tPV = 0, tW = 0, tB = 0, t0_ = O2_T(), t1_;
+  const unsigned tstart_ = t0_;
+#endif
+  // scores of tile t relative to `ref` (exp2 domain): S^T[kb] = K_kb . Q~^T - ref  (rows = keys in registers, column =
+  // query on the lane).  The two key blocks' chains are interleaved: a K fragment is consumed two MFMAs after the
+  // previous one of its chain, so its LDS read has twice the time to land.
+  // `init` (16 registers, all = -reference) is the C operand of both chains' first MFMA and stays live: no per-tile
+  // accumulator initialisation.
+  auto scores = [&](const char* sk, int t, const f32x16& init, f32x16 (&s)[2]) {
+#pragma unroll
+    for (int ds = 0; ds < C::NDS; ++ds)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], ds == 0 ? init : s[kb]);
+    if (RAGGED && t == nt - 1 && (L & 63)) {   // keys past the end of a ragged sequence get no weight
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) s[kb][r] = -1e30f;
+    }
+  };
+  auto rowmax = [&](const f32x16 (&s)[2]) {
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32));
+  };
+  {   // reference maximum of every row = its maximum over the first tile (one extra S product per workgroup row block)
+    f32x16 s0[2], zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    scores(smem, 0, zero, s0);
+    m_run = rowmax(s0);
+  }
+  // first tile of a super-tile: put the next super-tile in flight
+  auto stage_next = [&](int t) {
+    if (t % KT == 0 && (t / KT + 1) * KT < nt) stage_super(t / KT + 1, cur ^ 1);
+  };
+  // O^T[db] += V^T . (dropout(P))^T, then (last tile of a super-tile) the hand-over: next super-tile landed, everybody done
+  auto drop_pv_sync = [&](int t, const char* sv, f32x16 (&s)[2]) {
+    if (DROP) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        drop_keys_in_regs<true>(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][(t % KT) * 16 + hq * 8 + kb * 4]), thr);
+    }
+    O2_SEG(tSM)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = pack_frag(s[kb], ss);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+          o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
+      }
+    O2_SEG(tPV)
+    if (t % KT == KT - 1 || t == nt - 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      O2_SEG(tW)
+      __syncthreads();
+      O2_SEG(tB)
+      cur ^= 1;
+    }
+  };
+  // ---- fast loop: FIXED reference (the row's maximum over the first tile).  P, O and l share that one reference per row and
+  // fp32 / bf16 keep their relative precision at any scale, so as long as no probability relative to it overflows the result
+  // is exact -- and a score element costs one exp2, one add and its share of the bf16 conversion: no multiply, no
+  // subtraction, no row maximum, no rescale of O.  The row sums the loop computes anyway are the guard: a wave in which some
+  // half-row sum of a tile leaves [0, 2^40] (inf and NaN included) drops, from that tile on, to the safe loop below.
+  constexpr float FAST_LIMIT = 1.0995116e12f;      // 2^40
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+  int t = 0;
+  bool fast_ok = true;
+  for (; t < nt; ++t) {
+    const char* sk = smem + cur * STAGE + (t % KT) * 2 * C::TILE;
+    stage_next(t);
+    O2_SEG(tS)
+    f32x16 s[2];
+    scores(sk, t, negm, s);
+    O2_SEG(tQK)
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+        s[kb][r] = p;
+        psum += p;
+      }
+    if (__any(!(psum <= FAST_LIMIT))) { fast_ok = false; break; }     // wave-uniform; tile t is redone by the safe loop
+    l_run += psum;
+    drop_pv_sync(t, sk + C::TILE, s);
+  }
+  // ---- safe loop (only after the guard tripped; tile t + 1 is already in flight): online softmax with a moving reference,
+  // rescaled when some row of the wave outgrows it by more than 2^RESCALE_THR (wave-uniform, deferred: P is then bounded by
+  // 2^RESCALE_THR instead of 1; O and l use the same reference, the result is exact).
+  if (!fast_ok) {
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    bool staged = true;
+    for (; t < nt; ++t) {
+      const char* sk = smem + cur * STAGE + (t % KT) * 2 * C::TILE;
+      if (!staged) stage_next(t);
+      staged = false;
+      f32x16 s[2];
+      scores(sk, t, zero, s);
+      const float mt = rowmax(s);
+      constexpr float RESCALE_THR = 5.0f;
+      float alpha = 1.0f;
+      if (__any(mt > m_run + RESCALE_THR)) {
+        const float m_new = fmaxf(m_run, mt);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+          s[kb][r] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      drop_pv_sync(t, sk + C::TILE, s);
+    }
+  }
+#ifdef O2_STAMP
+  if (blockIdx.x < 64 && wave == 0 && lane == 0) {
+    unsigned* dd_ = o2_dbg_attn + blockIdx.x * 8;
+    dd_[0] = tS; dd_[1] = tQK; dd_[2] = tSM; dd_[3] = tPV; dd_[4] = tW; dd_[5] = tB; dd_[6] = O2_T() - tstart_; dd_[7] = (unsigned)nt;
+  }
+#endif
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
+  if (!q_ok) return;
+  if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+  bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dd = db * 32 + 8 * g4 + 4 * hq;
+      u32x2 w;
+      w[0] = pack_bf2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
+      w[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+      *reinterpret_cast<u32x2*>(orow + dd) = w;
+    }
+}
+
+// =============================================================================================
 // delta[b,h,q] = sum_d dO*O
 // =============================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
@@ -302,7 +551,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                             unsigned thr, float dscale, uint64_t seed_arg) {
+                                                             unsigned thr, float dscale, uint64_t seed_arg, float opmul) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];
@@ -320,18 +569,26 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
   const int qrow_raw = q0 + (lane & 31);
   const bool q_ok = !RAGGED || qrow_raw < L;
   const int qrow = q_ok ? qrow_raw : L - 1;
-  const float sc_log2 = scale * 1.4426950408889634f;
+  const float sc_log2 = opmul;     // multiplier of the register-resident S operand: log2(e)/sqrt(d), or 1 when q is stored pre-scaled
 
   bf16x8 qf[C::NDS], dof[C::NDS];
   const bf16_t* dorow = dout + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
 #pragma unroll
   for (int ds = 0; ds < C::NDS; ++ds) {
-    qf[ds] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq);
+    qf[ds] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq), sc_log2);
     dof[ds] = *reinterpret_cast<const bf16x8*>(dorow + ds * 16 + 8 * hq);
   }
   const size_t sidx = ((size_t)(b * H + head)) * L + qrow;
+  // Q enters the S MFMAs pre-multiplied by log2(e)/sqrt(d) and the S / dP accumulators START at -lse2 / -delta of the lane's
+  // row (two 16-register constant blocks, the C operands of every chain's first MFMA): S leaves the matrix pipe as the exp2
+  // argument and dP as dP - delta -- no multiply and no subtraction per score element.
   const float lse2 = lse[sidx] * 1.4426950408889634f;
   const float dlt = DROP ? delta[sidx] / dscale : delta[sidx];   // dscale folded into the final scale
+  // (d = 128 runs two waves per SIMD on 256 registers: only the S block fits there, dP - delta stays a subtraction)
+  constexpr bool DLT_INIT = (D != 128);
+  f32x16 nlse, ndlt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { nlse[r] = -lse2; ndlt[r] = DLT_INIT ? -dlt : 0.f; }
   const uint32_t rowhash = DROP ? o2_attn_rowhash(seed, (uint64_t)(b * H + head) * L + (uint64_t)qrow) : 0u;
 
   f32x16 dq[C::NDB];
@@ -360,19 +617,20 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
       for (int ds = 0; ds < C::NDS; ++ds) {
-        s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s);
-        dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], dp);
+        s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], ds == 0 ? nlse : s);
+        dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], ds == 0 ? ndlt : dp);
       }
-      if (DROP) drop_keys_in_regs<false>(dp, rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr);
+      // a dropped element: (0 - delta) instead of (dP - delta)
+      if (DROP)
+        drop_keys_in_regs<false>(dp, rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][hq * 8 + kb * 4]), thr,
+                                 DLT_INIT ? -dlt : 0.f);
       const bool tail = RAGGED && (t == nt - 1) && (L & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse2);
+        float p = __builtin_amdgcn_exp2f(s[r]);
         if (tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) p = 0.f;   // key past the end
-        s[r] = p * (dp[r] - dlt);  // dS^T
+        s[r] = DLT_INIT ? p * dp[r] : p * (dp[r] - dlt);  // dS^T
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -413,7 +671,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                              unsigned thr, float dscale, uint64_t seed_arg) {
+                                                              unsigned thr, float dscale, uint64_t seed_arg, float opmul,
+                                                              float kgrad) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   constexpr bool DO_DK = WHICH != 2, DO_DV = WHICH != 1;
@@ -433,13 +692,13 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
   const int krow_raw = k0 + (lane & 31);
   const bool k_ok = !RAGGED || krow_raw < L;
   const int krow = k_ok ? krow_raw : L - 1;
-  const float sc_log2 = scale * 1.4426950408889634f;
+  const float sc_log2 = opmul;     // multiplier of the register-resident S operand: log2(e)/sqrt(d), or 1 when q is stored pre-scaled
   float* sstat = reinterpret_cast<float*>(smem + 4 * C::TILE);
 
   bf16x8 kf[C::NDS], vf[DO_DK ? C::NDS : 1];
 #pragma unroll
   for (int ds = 0; ds < C::NDS; ++ds) {
-    kf[ds] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
+    kf[ds] = scale_frag(*reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq), sc_log2);
     if (DO_DK) vf[ds] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
   }
   f32x16 dk[DO_DK ? C::NDB : 1], dv[DO_DV ? C::NDB : 1];
@@ -464,7 +723,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
                   : lse[sbase + t * 64 + i] * 1.4426950408889634f;
       else
         v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
-      sstat[(buf * 3 + which) * 64 + i] = v;
+      sstat[(buf * 3 + which) * 64 + i] = -v;   // stored NEGATED: the S and dP accumulators start from these rows
     } else if (DROP && tid < 192) {   // dropout: hashes of the tile's 64 query rows
       const int i = tid & 63;
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
@@ -490,12 +749,20 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
     const uint32_t* s_rh = reinterpret_cast<const uint32_t*>(sstat) + (cur * 3 + 2) * 64;
     // the dV-only pass has a single chain per query block (S = Q.K^T): run both blocks' chains interleaved so each
     // Q fragment's LDS read gets two MFMAs of time to land (the dK pass interleaves its S and dP chains instead)
+    // (K is pre-multiplied by log2(e)/sqrt(d) and the accumulators START at -lse2[q] / -delta[q], read from the tile's LDS
+    //  table: S leaves the matrix pipe as the exp2 argument, dP as dP - delta)
+    auto init_rows = [&](const float* tab, int qb, f32x16& x) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(tab + qb * 32 + 8 * g4 + 4 * hq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[4 * g4 + e] = v4[e];
+      }
+    };
     f32x16 s_pre[(!DO_DK) ? 2 : 1];
     if (!DO_DK) {
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_pre[qb][r] = 0.f;
+      for (int qb = 0; qb < 2; ++qb) init_rows(s_lse, qb, s_pre[qb]);
 #pragma unroll
       for (int ds = 0; ds < C::NDS; ++ds)
 #pragma unroll
@@ -507,8 +774,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
       // S[q x key] = Q . K^T, dP[q x key] = dO . V^T  (rows = queries in registers, column = key on the lane)
       f32x16 s, dp;
       if (DO_DK) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        init_rows(s_lse, qb, s);
+        init_rows(s_dlt, qb, dp);
 #pragma unroll
         for (int ds = 0; ds < C::NDS; ++ds) {
           s = MFMA32(row_frag<D>(sq, qb * 32 + (lane & 31), ds, hq), kf[ds], s);
@@ -534,23 +801,22 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
       f32x16 pd;  // P after dropout (for dV)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(s_lse + qb * 32 + 8 * g4 + 4 * hq);
-        f32x4 dl4 = {0.f, 0.f, 0.f, 0.f};
-        if (DO_DK) dl4 = *reinterpret_cast<const f32x4*>(s_dlt + qb * 32 + 8 * g4 + 4 * hq);
+        f32x4 ndl4 = {0.f, 0.f, 0.f, 0.f};
+        if (DO_DK && DROP) ndl4 = *reinterpret_cast<const f32x4*>(s_dlt + qb * 32 + 8 * g4 + 4 * hq);   // -delta
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g4 + e;
-          float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse4[e]);
-          float dpr = dp[r];
+          float p = __builtin_amdgcn_exp2f(s[r]);
+          float dpr = dp[r];            // dP - delta
           float pdr = p;
           if (DROP) {
             const uint32_t hh = quad_bcast(hmine[g4], e);
             const bool keep = ((hh >> kbyte) & 0xffu) >= thr;
-            dpr = keep ? dpr : 0.f;     // dscale is applied once, on the final dK / dV tiles
+            dpr = keep ? dpr : ndl4[e];     // a dropped element: 0 - delta  (dscale is applied once, on the final dK / dV tiles)
             pdr = keep ? p : 0.f;
           }
           if (DO_DV) pd[r] = pdr;
-          if (DO_DK) s[r] = p * (dpr - dl4[e]);  // dS
+          if (DO_DK) s[r] = p * dpr;  // dS
         }
       }
 #pragma unroll
@@ -583,7 +849,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
       const int dd = db * 32 + 8 * g4 + 4 * hq;
       u32x2 w;
       if (DO_DK) {
-        const float fk = DROP ? scale * dscale : scale;
+        const float fk = DROP ? kgrad * dscale : kgrad;    // 1/sqrt(d), or ln 2 when the Q rows in LDS are pre-scaled
         w[0] = pack_bf2(dk[db][4 * g4] * fk, dk[db][4 * g4 + 1] * fk);
         w[1] = pack_bf2(dk[db][4 * g4 + 2] * fk, dk[db][4 * g4 + 3] * fk);
         *reinterpret_cast<u32x2*>(dkrow + dd) = w;
@@ -607,21 +873,14 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
 //   * the dropout byte test is (word & bytemask) >= (thr << kbyte) on the quad-broadcast word (v_and_b32_dpp + v_cmp).
 // Results are bit-identical to the split passes (same per-element arithmetic and accumulation order).
 // =============================================================================================
-// two floats -> packed bf16 pair as ONE v_cvt_pk_bf16_f32 (the shift-and-or form of pack_bf2 costs three more instructions)
-__device__ __forceinline__ unsigned cvt_pk_bf2(float lo, float hi) {
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  const f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-
 template <bool DROP, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* __restrict__ qkv,
                                                                  const bf16_t* __restrict__ dout,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta,
                                                                  bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                                 unsigned thr, float dscale, uint64_t seed_arg) {
+                                                                 unsigned thr, float dscale, uint64_t seed_arg, float opmul,
+                                                                 float kgrad) {
   constexpr int D = 128, NW = 8;
   using C = Cfg<D>;
   constexpr int VOFF = 4 * C::TILE, SOFF = 8 * C::TILE;       // [2][Q|dO] | V rows of the workgroup | [2][lse2|delta|row hash]
@@ -642,13 +901,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
   const int krow_raw = k0 + (lane & 31);
   const bool k_ok = !RAGGED || krow_raw < L;
   const int krow = k_ok ? krow_raw : L - 1;
-  const float sc_log2 = scale * 1.4426950408889634f;
+  const float sc_log2 = opmul;     // multiplier of the register-resident S operand: log2(e)/sqrt(d), or 1 when q is stored pre-scaled
   float* sstat = reinterpret_cast<float*>(smem + SOFF);
 
   bf16x8 kf[C::NDS];
 #pragma unroll
   for (int ds = 0; ds < C::NDS; ++ds)
-    kf[ds] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq);
+    kf[ds] = scale_frag(*reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq), sc_log2);
 #pragma unroll
   for (int j = 0; j < NW / 2; ++j) {
     int start = tile_i * (NW * 32) + j * 64, nv = L - start;
@@ -699,7 +958,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
                   : lse[sbase + t * 64 + i] * 1.4426950408889634f;
       else
         v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
-      sstat[(buf * 3 + which) * 64 + i] = v;
+      sstat[(buf * 3 + which) * 64 + i] = -v;   // stored NEGATED: the S and dP accumulators start from these rows
     } else if (DROP && tid < 192) {   // dropout: hashes of the tile's 64 query rows
       const int i = tid & 63;
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
@@ -723,9 +982,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       // S[q x key] = Q . K^T, dP[q x key] = dO . V^T  (rows = queries in registers, column = key on the lane)
+      // The accumulators START at -lse2[q] and -delta[q] (read from the tile's LDS table straight into them): with K
+      // pre-multiplied by log2(e)/sqrt(d), S leaves the matrix pipe as the exp2 argument and dP as dP - delta.
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 0) * 64 + qb * 32 + 8 * g4);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 1) * 64 + qb * 32 + 8 * g4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a4[e]; dp[4 * g4 + e] = c4[e]; }
+      }
       int vw = vwoff;
       asm volatile("" : "+s"(vw));          // keep the 8 V addresses out of registers: one v_add per read instead
       // one k-step of operands in flight (12 registers), pinned: hipcc otherwise prefetches all 24 fragments (96 registers)
@@ -754,23 +1020,23 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
       u32x4 pfw[2], dsw[2];     // P after dropout (for dV) and dS (for dK) as the operands of k-steps ss = 0, 1
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 0) * 64 + qb * 32 + 8 * g4);
-        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 1) * 64 + qb * 32 + 8 * g4);
+        f32x4 ndl4 = {0.f, 0.f, 0.f, 0.f};
+        if (DROP) ndl4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 1) * 64 + qb * 32 + 8 * g4);   // -delta
         float pv[4], dsv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g4 + e;
-          const float p = __builtin_amdgcn_exp2f(s[r] * sc_log2 - lse4[e]);
-          float dpr = dp[r];
+          const float p = __builtin_amdgcn_exp2f(s[r]);
+          float dpr = dp[r];            // dP - delta
           float pdr = p;
           if (DROP) {
             const bool keep = (quad_bcast(hmine[g4], e) & bmask) >= thrs;
-            dpr = keep ? dpr : 0.f;     // dscale is applied once, on the final dK / dV tiles
+            dpr = keep ? dpr : ndl4[e];     // a dropped element: 0 - delta  (dscale is applied once, on the final dK / dV tiles)
             pdr = keep ? p : 0.f;
             asm volatile("" : "+v"(pdr));   // select in fp32, then convert pairs (else: single converts + v_perm merges)
           }
           pv[e] = pdr;
-          dsv[e] = p * (dpr - dl4[e]);  // dS
+          dsv[e] = p * dpr;  // dS
         }
         pfw[g4 >> 1][2 * (g4 & 1)] = cvt_pk_bf2(pv[0], pv[1]);
         pfw[g4 >> 1][2 * (g4 & 1) + 1] = cvt_pk_bf2(pv[2], pv[3]);
@@ -809,7 +1075,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
   if (!k_ok) return;
   bf16_t* dkrow = dqkv + ((size_t)b * L + krow) * tstride + (size_t)H * D + (size_t)head * D;
   bf16_t* dvrow = dkrow + (size_t)H * D;
-  const float fk = DROP ? scale * dscale : scale, fv = DROP ? dscale : 1.0f;
+  const float fk = DROP ? kgrad * dscale : kgrad, fv = DROP ? dscale : 1.0f;    // kgrad: 1/sqrt(d), or ln 2 (pre-scaled Q)
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
@@ -843,22 +1109,23 @@ static int attn_check(const void* a, const void* b, int B, int L, int H, int d, 
 }
 
 // waves per workgroup: 8 (256-row tiles, K/V or Q/dO tiles shared by twice the waves) whenever the sequence has at least
-// one such tile and the kernel fits two waves per SIMD (d = 64, 128); $ORBIT2_ATTN_WAVES=4 keeps the round-1 geometry (A/B)
-static int attn_waves(int L, int d) {
+// one such tile and the kernel fits two waves per SIMD (d = 64, 128); ORBIT2_ATTN_4WAVES keeps the round-1 geometry (A/B).
+// The variant is an ARGUMENT of the *_ex entry points (no process-global switch: a forward / backward pair cannot disagree
+// behind the caller's back, nothing is read from the environment on the launch path).
+static int attn_waves(int L, int d, int flags) {
   if (d == 256 || L < 256) return 4;
-  const char* e = getenv("ORBIT2_ATTN_WAVES");
-  return (e && e[0] == '4') ? 4 : 8;
-}
-
-static bool attn_fused_dkv() {           // d = 128: dK and dV in one pass; $ORBIT2_ATTN_DKV=split keeps the two-pass form (A/B)
-  const char* e = getenv("ORBIT2_ATTN_DKV");
-  return !(e && e[0] == 's');
+  return (flags & ORBIT2_ATTN_4WAVES) ? 4 : 8;
 }
 
 template <int DV, bool DR, bool RG, int NW>
 static void launch_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, float sc_log2, unsigned thr, float dscale,
                        uint64_t seed, hipStream_t s) {
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
+  if constexpr (!DR) {
+    hipLaunchKernelGGL((attn_fwd_lazy_kernel<DV, RG, NW>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
+                       thr, dscale, seed);
+    return;
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, RG, NW>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
                      thr, dscale, seed);
 }
@@ -871,14 +1138,20 @@ static void launch_fwd_r(bool ragged, const void* qkv, void* out, float* lse, in
 
 extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
                                uint64_t seed, void* stream) {
+  return orbit2_attn_fwd_ex(qkv, out, lse, B, L, H, d, drop_p, seed, 0, stream);
+}
+
+extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
+                                  uint64_t seed, int flags, void* stream) {
   int rc = attn_check(qkv, out, B, L, H, d, drop_p);
   if (rc) return rc;
   if (!lse) return O2_ERR_ARG;
-  const float sc_log2 = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
+  // (q stored pre-scaled: the kernels' multiplier is 1)
+  const float sc_log2 = (flags & ORBIT2_ATTN_Q_PRESCALED) ? 1.0f : (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
   hipStream_t s = (hipStream_t)stream;
-  const int nw = attn_waves(L, d);
+  const int nw = attn_waves(L, d, flags);
   const bool ragged = (L % (nw * 32)) != 0;
 #define O2_FWD(DV, NWV)                                                                              \
   do {                                                                                               \
@@ -895,37 +1168,46 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
 
 template <int DV, bool DR, bool RG, int NW>
 static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta, bf16_t* dq_, int B, int L,
-                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s) {
+                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s, int flags) {
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
+  const bool pre = (flags & ORBIT2_ATTN_Q_PRESCALED) != 0;
+  const float opmul = pre ? 1.0f : scale * 1.4426950408889634f, kgrad = pre ? 0.6931471805599453f : scale;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                     seed);
+                     seed, opmul);
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed);
-  } else if (DV == 128 && NW == 8 && attn_fused_dkv()) {   // one pass, V rows in LDS
+                       dscale, seed, opmul, kgrad);
+  } else if (DV == 128 && NW == 8 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {   // one pass, V rows in LDS
     hipLaunchKernelGGL((attn_bwd_dkv128_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                       seed);
+                       seed, opmul, kgrad);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 1, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed);
+                       dscale, seed, opmul, kgrad);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 2, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed);
+                       dscale, seed, opmul, kgrad);
   }
 }
 template <int DV, int NW>
 static void launch_bwd_r(bool drop, bool ragged, const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta,
-                         bf16_t* dq_, int B, int L, int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s) {
+                         bf16_t* dq_, int B, int L, int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s,
+                         int flags) {
   if (drop) {
-    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
-    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
   } else {
-    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
-    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
   }
 }
 
 extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                                void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, void* stream) {
+  return orbit2_attn_bwd_ex(qkv, out, dout, lse, delta, dqkv, B, L, H, d, drop_p, seed, 0, stream);
+}
+
+extern "C" int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                  void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, int flags,
+                                  void* stream) {
   int rc = attn_check(qkv, out, B, L, H, d, drop_p);
   if (rc) return rc;
   if (!dout || !lse || !delta || !dqkv) return O2_ERR_ARG;
@@ -940,15 +1222,15 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
   const bf16_t* q_ = (const bf16_t*)qkv;
   const bf16_t* do_ = (const bf16_t*)dout;
   bf16_t* dq_ = (bf16_t*)dqkv;
-  const int nw = attn_waves(L, d);
+  const int nw = attn_waves(L, d, flags);
   const bool ragged = (L % (nw * 32)) != 0;
-  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
   else if (d == 128) {
-    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
-    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
   } else {
-    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
-    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s);
+    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
   }
   O2_CHECK_LAUNCH();
   return O2_OK;

@@ -78,6 +78,8 @@ struct Epi {
   int M, N, ldc, ldr, res_mod, res_first, rows_per_scale, act, out_fp32;
   unsigned thr;
   float dscale, beta;
+  int colscale_n;      // columns n < colscale_n are multiplied by colscale right after the bias (0: none)
+  float colscale;
 };
 
 __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
@@ -87,6 +89,10 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
     const u32x2 b = *reinterpret_cast<const u32x2*>(e.bias + n);
     v[0] += bf2f((bf16_t)(b[0] & 0xffff)); v[1] += bf2f((bf16_t)(b[0] >> 16));
     v[2] += bf2f((bf16_t)(b[1] & 0xffff)); v[3] += bf2f((bf16_t)(b[1] >> 16));
+  }
+  if (n < e.colscale_n) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= e.colscale;
   }
   if (e.save_pre) {
     u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
@@ -187,6 +193,10 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
   if (e.bias) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+  }
+  if (n < e.colscale_n) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= e.colscale;
   }
   if (e.save_pre) {
     const u32x4 o = pack8(v);
@@ -776,6 +786,9 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return O2_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
+  if (a->colscale_n < 0 || a->colscale_n % 8) return O2_ERR_ARG;
+  e.colscale_n = a->colscale_n;
+  e.colscale = a->colscale;
   e.bias = (const bf16_t*)a->bias;
   e.save_pre = (bf16_t*)a->save_pre;
   e.dgelu_pre = (const bf16_t*)a->dgelu_pre;

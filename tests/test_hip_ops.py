@@ -160,6 +160,29 @@ def test_gemm_epilogue_full(hip, tile):
     assert nerr(dgb, (A @ W.t()) * mask * sc * prq.grad) < 6e-3
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_column_scale(hip, tile):
+    """colscale epilogue (the qkv Linear's q third times log2(e)/sqrt(d)): columns n < colscale_n are multiplied in fp32
+    right after the bias -- one rounding to bf16 -- the rest are untouched bit for bit; fp32 and bf16 outputs"""
+    M, N, K, n0, c = 256, 384, 128, 128, 0.12752041
+    g = torch.Generator().manual_seed(6)
+    A, W, bias = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.2), rt(torch.randn(N, generator=g))
+    ref = A @ W.t() + bias
+    ref[:, :n0] *= c
+    plain = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), plain, M, N, K, K, K, N, bias=bf(bias).cuda(), tile=tile)
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 6e-3)):
+        out = torch.empty(M, N, dtype=dt, device="cuda")
+        hip.gemm(bf(A).cuda(), bf(W).cuda(), out, M, N, K, K, K, N, bias=bf(bias).cuda(), tile=tile, colscale=(n0, c))
+        assert nerr(out[:, :n0], ref[:, :n0]) < tol and nerr(out[:, n0:], ref[:, n0:]) < tol
+        if dt == torch.bfloat16:
+            assert torch.equal(out[:, n0:], plain[:, n0:])
+            # ONE rounding: bf16(fp32 value * c), not bf16(bf16(value) * c)
+            assert torch.equal(out[:, :n0].cpu(), bf((A @ W.t() + bias)[:, :n0] * c)) or nerr(out[:, :n0], ref[:, :n0]) < 4e-3
+    with pytest.raises(hip.HipBackendError):
+        hip.gemm(bf(A).cuda(), bf(W).cuda(), plain, M, N, K, K, K, N, colscale=(4, c))      # not a multiple of 8
+
+
 def test_dropout_statistics(hip):
     M, N = 512, 1024
     dy = torch.ones(M, N, dtype=torch.bfloat16, device="cuda")
@@ -255,39 +278,94 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attention_dkv_one_pass_equals_two_passes(hip, L, p):
     """d = 128, >= 256 tokens: dK and dV come from ONE pass (V rows in LDS, csrc/attn.hip attn_bwd_dkv128_kernel); the
-    two-pass kernels stay selectable ($ORBIT2_ATTN_DKV=split) and must give the same bits -- odd tile counts (L = 300:
-    5 tiles, the pair loop's sixth is past the end) and ragged tails included"""
-    import os
+    two-pass kernels stay selectable (flag ORBIT2_ATTN_SPLIT_DKV of orbit2_attn_bwd_ex) and must give the same bits -- odd
+    tile counts (L = 300: 5 tiles, the pair loop's sixth is past the end) and ragged tails included"""
     B, H, d = 2, 3, 128
     g = torch.Generator().manual_seed(L)
     qkv = bf(torch.randn(B, L, 3 * H * d, generator=g) * 0.7).cuda()
     do = bf(torch.randn(B, L, H * d, generator=g)).cuda()
     out, lse = hip.attn_fwd(qkv, B, L, H, d, p, 4242)
     one = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, 4242)
-    os.environ["ORBIT2_ATTN_DKV"] = "split"
-    try:
-        two = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, 4242)
-    finally:
-        os.environ.pop("ORBIT2_ATTN_DKV", None)
+    two = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, 4242, flags=hip.ATTN_SPLIT_DKV)
     assert torch.equal(one, two)
 
 
-def test_attention_forced_late_rescale(hip):
-    """The forward defers its running-max rescale (csrc/attn.hip RESCALE_THR); force the branch late in the key
-    loop: one key far down the sequence matches every query strongly, so the row max jumps by >> 2^5 there."""
+LOG2E = 1.4426950408889634
+
+
+def _prescale_q(qkv, B, L, H, d):
+    """what the qkv GEMM's colscale epilogue stores: the q third times log2(e)/sqrt(d), rounded to bf16 ONCE; returns
+    (stored tensor, the fp32 qkv it represents exactly)"""
+    x = qkv.view(B, L, 3, H * d).clone()
+    x[:, :, 0] = (x[:, :, 0] * (LOG2E / d ** 0.5)).to(torch.bfloat16).float()
+    stored = x.reshape(B, L, 3 * H * d)
+    eff = x.clone()
+    eff[:, :, 0] = eff[:, :, 0] / (LOG2E / d ** 0.5)
+    return bf(stored), eff.reshape(B, L, 3 * H * d)
+
+
+@pytest.mark.parametrize("prescaled", [True, False])
+@pytest.mark.parametrize("mult,min_jump_bits", [(60.0, 8.0), (1200.0, 45.0), (4000.0, 130.0)])
+def test_attention_forced_late_rescale(hip, mult, min_jump_bits, prescaled):
+    """The no-dropout forward keeps ONE reference per row (its maximum over the first 64 keys) while the probabilities
+    relative to it stay below 2^40 (csrc/attn.hip FAST_LIMIT) and drops to an online-softmax loop with a moving reference
+    (RESCALE_THR) once they do not.  Force both: one key far down the sequence matches every query strongly, so the row
+    maximum jumps there by ~11 bits (stays on the fixed reference: probabilities up to 2^11), by ~66 bits (the guard trips)
+    and by > 128 bits (exp2 overflows to inf in the fast loop before the guard trips).
+    prescaled: q stored as q * log2(e)/sqrt(d) (flag ORBIT2_ATTN_Q_PRESCALED, what the model's qkv GEMM writes): exact
+    products, tight tolerance.  Raw q: the kernel rounds q * log2(e)/sqrt(d) to bf16 itself, a second rounding whose effect on
+    a score grows with the score (~2^-9 |s| / sqrt(d)): at these artificial magnitudes (tens to hundreds of nats) percents."""
     B, L, H, d = 1, 512, 2, 128
     g = torch.Generator().manual_seed(77)
     qkv = torch.randn(B, L, 3, H, d, generator=g) * 0.5
-    qkv[:, 300, 1] = qkv[:, :, 0].mean(1) * 60 + 3.0        # a key aligned with the mean query, scaled up
+    qkv[:, 300, 1] = qkv[:, :, 0].mean(1) * mult + 3.0        # a key aligned with the mean query, scaled up
     qkv[:, 450, 1] *= 12.0
     qkv = rt(qkv.reshape(B, L, 3 * H * d))
+    if prescaled:
+        stored, qkv = _prescale_q(qkv, B, L, H, d)
+        out, lse = hip.attn_fwd(stored.cuda(), B, L, H, d, 0.0, 0, flags=hip.ATTN_Q_PRESCALED)
+    else:
+        out, lse = hip.attn_fwd(bf(qkv).cuda(), B, L, H, d, 0.0, 0)
     ref = _attn_ref(qkv, B, L, H, d)
-    out, lse = hip.attn_fwd(bf(qkv).cuda(), B, L, H, d, 0.0, 0)
     q, k, _ = qkv.view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
     sc = (q * d ** -0.5) @ k.transpose(-2, -1)
-    assert float((sc.max(-1).values - sc[..., :256].max(-1).values).max()) > 5.0   # the max really jumps late (> 2^5 in the exp2 domain)
+    jump_bits = float((sc.max(-1).values - sc[..., :64].max(-1).values).max()) * LOG2E
+    assert jump_bits > min_jump_bits     # the maximum really jumps that late, by that much (exp2 domain)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert nerr(out, ref) < (1e-2 if prescaled else 8e-2)
+    assert nerr(lse, torch.logsumexp(sc, -1)) < (1e-3 if prescaled else 3e-3)
+
+
+@pytest.mark.parametrize("d,H,L,B", [(64, 2, 192, 2), (128, 3, 384, 1), (128, 2, 300, 1), (256, 1, 161, 1)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_q_prescaled(hip, d, H, L, B, p):
+    """flag ORBIT2_ATTN_Q_PRESCALED: the q third of qkv holds q * log2(e)/sqrt(d) (the qkv GEMM's colscale epilogue);
+    out / lse are those of the q it represents, dqkv is the gradient with respect to the UNSCALED q, k, v"""
+    g = torch.Generator().manual_seed(3 * d + L)
+    stored, eff = _prescale_q(rt(torch.randn(B, L, 3 * H * d, generator=g)), B, L, H, d)
+    eff.requires_grad_()
+    do = rt(torch.randn(B, L, H * d, generator=g))
+    seed = 424242
+    mask, sc = None, 1.0
+    if p > 0:
+        m, sc = attn_keep_mask(seed, B * H, L, p)
+        mask = torch.from_numpy(m).view(B, H, L, L)
+    ref = _attn_ref(eff, B, L, H, d, mask, sc)
+    ref.backward(do)
+    out, lse = hip.attn_fwd(stored.cuda(), B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED)
     assert nerr(out, ref) < 1e-2
-    assert nerr(lse, torch.logsumexp(sc, -1)) < 1e-3
+    q, k, _ = eff.detach().view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    assert nerr(lse, torch.logsumexp((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1)) < 1e-3
+    dqkv = hip.attn_bwd(stored.cuda(), out, bf(do).cuda(), lse, B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED)
+    gr = eff.grad.view(B, L, 3, H * d)
+    dv = dqkv.view(B, L, 3, H * d)
+    for i, nm in enumerate("qkv"):
+        assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
+    # both variants of the d = 128 dK+dV pass agree bit for bit with the flag as well
+    if d == 128 and L >= 256:
+        two = hip.attn_bwd(stored.cuda(), out, bf(do).cuda(), lse, B, L, H, d, p, seed,
+                           flags=hip.ATTN_Q_PRESCALED | hip.ATTN_SPLIT_DKV)
+        assert torch.equal(dqkv, two)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""8-wave (256-row workgroups, default) vs 4-wave (ORBIT2_ATTN_WAVES=4, the round-1 geometry) attention kernels: equality of
+"""8-wave (256-row workgroups, default) vs 4-wave (flag ORBIT2_ATTN_4WAVES of the *_ex entries, the round-1 geometry) attention kernels: equality of
 the results (the per-wave arithmetic is the same: bit-identical) and interleaved timing at the interm_1b / interm_117m shapes."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,10 +6,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "orbit-2_amd")]
 import torch
 from climate_learn import _hip
 
-def run(nw, f):
-    if nw == 4: os.environ["ORBIT2_ATTN_WAVES"] = "4"
-    else: os.environ.pop("ORBIT2_ATTN_WAVES", None)
-    return f()
+def fl(nw):
+    return _hip.ATTN_4WAVES if nw == 4 else 0
 
 def t(f, n=4):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,8 +24,8 @@ for (H, L, d, Bx) in [(24, 8192, 128, B), (16, 4096, 64, B), (2, 256 + 96, 64, 2
     for p in (0.0, 0.1):
         res = {}
         for nw in (4, 8):
-            out, lse = run(nw, lambda: _hip.attn_fwd(qkv, Bx, L, H, d, p, 11))
-            dqkv = run(nw, lambda: _hip.attn_bwd(qkv, out, do, lse, Bx, L, H, d, p, 11))
+            out, lse = _hip.attn_fwd(qkv, Bx, L, H, d, p, 11, flags=fl(nw))
+            dqkv = _hip.attn_bwd(qkv, out, do, lse, Bx, L, H, d, p, 11, flags=fl(nw))
             res[nw] = (out, lse, dqkv)
         torch.cuda.synchronize()
         same = all(torch.equal(a, b) for a, b in zip(res[4], res[8]))
@@ -38,10 +36,10 @@ for (H, L, d, Bx) in [(24, 8192, 128, B), (16, 4096, 64, B), (2, 256 + 96, 64, 2
         tf, tb = {4: [], 8: []}, {4: [], 8: []}
         for rnd in range(3):
             for nw in (4, 8):
-                tf[nw].append(run(nw, lambda: t(lambda: _hip.attn_fwd(qkv, Bx, L, H, d, p, 11))))
-                tb[nw].append(run(nw, lambda: t(lambda: _hip.attn_bwd(qkv, res[8][0], do, res[8][1], Bx, L, H, d, p, 11))))
-        fl = 4.0 * Bx * H * L * L * d / 1e9
+                tf[nw].append(t(lambda: _hip.attn_fwd(qkv, Bx, L, H, d, p, 11, flags=fl(nw))))
+                tb[nw].append(t(lambda: _hip.attn_bwd(qkv, res[8][0], do, res[8][1], Bx, L, H, d, p, 11, flags=fl(nw))))
+        gf = 4.0 * Bx * H * L * L * d / 1e9
         print("   fwd: 4-wave %7.3f ms %5.0f TF | 8-wave %7.3f ms %5.0f TF (%+.1f %%)   bwd: 4-wave %7.3f ms %5.0f TF | 8-wave %7.3f ms %5.0f TF (%+.1f %%)"
-              % (med(tf[4]), fl / med(tf[4]), med(tf[8]), fl / med(tf[8]), 100 * (med(tf[4]) / med(tf[8]) - 1),
-                 med(tb[4]), 2 * fl / med(tb[4]), med(tb[8]), 2 * fl / med(tb[8]), 100 * (med(tb[4]) / med(tb[8]) - 1)), flush=True)
+              % (med(tf[4]), gf / med(tf[4]), med(tf[8]), gf / med(tf[8]), 100 * (med(tf[4]) / med(tf[8]) - 1),
+                 med(tb[4]), 2 * gf / med(tb[4]), med(tb[8]), 2 * gf / med(tb[8]), 100 * (med(tb[4]) / med(tb[8]) - 1)), flush=True)
 print("ALL OK" if ok else "MISMATCH")

@@ -8,14 +8,14 @@ import torch
 from climate_learn import _hip
 B, L, H, d = 4, 8192, 24, 128
 for mode in ("plain8", "plain4"):
-    if mode == "plain4": os.environ["ORBIT2_ATTN_WAVES"] = "4"
+    fl = _hip.ATTN_4WAVES if mode == "plain4" else 0
     for p in (0.0, 0.1):
         qkv = (torch.randn(B, L, 3, H, d, device="cuda") * 0.5).to(torch.bfloat16)
         for _ in range(2):
-            _hip.attn_fwd(qkv, B, L, H, d, p, 7)
+            _hip.attn_fwd(qkv, B, L, H, d, p, 7, flags=fl)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); _hip.attn_fwd(qkv, B, L, H, d, p, 7); e1.record(); torch.cuda.synchronize()
+        e0.record(); _hip.attn_fwd(qkv, B, L, H, d, p, 7, flags=fl); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         buf = (C.c_uint * (64 * 8))()
         _hip.lib().orbit2_debug_read_attn(buf, 64 * 8)

@@ -141,8 +141,47 @@ def mfma(path, out):
             f.write("%-58s %6d %10.3f %11.1f%% %10.2f\n" % (k[:58], n, ns / 1e6, 100 * util, gui / 8.0 / ns))
 
 
+def sq(dirpath, out):
+    """every *_counter_collection.csv under dirpath (SQ passes of tools/attn_pmc.sh) -> per kernel (full template name):
+    per-dispatch averages of each counter, plus ratios against SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE where they exist."""
+    import glob, os
+    agg = collections.OrderedDict()
+    for path in sorted(glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True)):
+        per = {}
+        for r in csv.DictReader(open(path)):
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            k = k[: k.index("(")] if "(" in k else k
+            d = per.setdefault((r["Dispatch_Id"], k), {"ns": float(r["End_Timestamp"]) - float(r["Start_Timestamp"])})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for (_, k), d in per.items():
+            a = agg.setdefault(k, collections.defaultdict(list))
+            for c, v in d.items():
+                a[c].append(v)
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc SQ passes, per-dispatch averages (chip totals); source dir %s\n" % dirpath)
+        for k, d in agg.items():
+            if not any(s_ in k for s_ in ("gemm", "attn")) or "delta" in k:
+                continue
+            avg = {c: sum(v) / len(v) for c, v in d.items()}
+            f.write("%s   [%.3f ms, n=%d]\n" % (k[:110], avg["ns"] / 1e6, len(d["ns"])))
+            wc = avg.get("SQ_WAVE_CYCLES")
+            gui = avg.get("GRBM_GUI_ACTIVE")
+            for c in sorted(avg):
+                if c == "ns":
+                    continue
+                extra = ""
+                if wc and c.startswith("SQ_") and c not in ("SQ_WAVE_CYCLES", "SQ_WAVES") and ("CYCLES" in c or "WAIT" in c or "ACTIVE" in c):
+                    extra += "  %5.1f %% of SQ_WAVE_CYCLES" % (100 * avg[c] / wc)
+                if gui and c == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    extra += "  matrix pipe busy %.1f %%, clock %.2f GHz" % (100 * avg[c] / (gui / 8 * 1024), gui / 8 / avg["ns"])
+                f.write("    %-34s %18.0f%s\n" % (c, avg[c], extra))
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
+    if mode == "sq":
+        sq(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     if mode == "mfma":
         mfma(sys.argv[2], sys.argv[3])
         sys.exit(0)
