@@ -19,6 +19,7 @@ for p in (ROOT, os.path.join(ROOT, "orbit-2_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -65,6 +66,9 @@ def parse():
     ap.add_argument("--daymet", action="store_true",
                     help="BASELINE configs[4] / SURVEY 8d-5: 7 Daymet-like inputs, 3 outputs, hybrid perceptual loss "
                          "(use --grid 96x192); not the headline configuration")
+    ap.add_argument("--daymet-loss", default="perceptual_lat_mse", choices=["perceptual_lat_mse", "perceptual"],
+                    help="loss of the --daymet configuration: the hybrid perceptual + latitude-weighted MSE sum BASELINE "
+                         "configs[4] names (default), or the reference's `perceptual` object alone")
     ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="replay zero_grad+forward+loss+backward (+bucket all-reduces) from one captured hipGraph; auto "
                          "(default): on when a step has <= 16384 tokens per GPU (launch-bound small configurations), off "
@@ -309,7 +313,7 @@ def main():
     drop = 0.0 if a.no_dropout else 0.1
     tp = a.tensor_par
     capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
-    capturable = capturable and not a.daymet and not a.fsdp     # perceptual loss: host read in backward; fsdp: host-driven gathers
+    capturable = capturable and not a.fsdp     # fsdp: host-driven gathers (the perceptual loss keeps its scalar on the device now)
     a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable)
     if tp > 1 and (world % tp or a.graph):
         raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)
@@ -336,9 +340,9 @@ def main():
         blk.recompute = a.recompute
     nparams = sum(p.numel() for p in model.parameters())
     if a.fsdp:
-        if tp > 1 or a.graph:
-            raise SystemExit("--fsdp runs without tensor parallelism and without hipGraph replay")
-        eng = cl.HipFullyShardedDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential))
+        if a.graph:
+            raise SystemExit("--fsdp runs without hipGraph replay")
+        eng = cl.HipFullyShardedDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential), tp_group=tp_group)
     else:
         eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
                                  shard_optimizer=a.shard_optimizer, replica_group=tp_group)
@@ -347,7 +351,11 @@ def main():
     loss_fn = Bayesian_TV(aggregate_only=True)
     if a.daymet:
         os.environ.setdefault("ORBIT2_LPIPS_SYNTHETIC", "1")    # throughput run: seeded stand-in LPIPS-VGG16 weights, opt-in
-        loss_fn = cl.load_loss(dev, None, "perceptual", True, None)      # L1 + 0.5 LPIPS-VGG16
+        # BASELINE configs[4] / SURVEY 8d-5: "hybrid perceptual + lat-weighted MSE": L1 + 0.5 LPIPS-VGG16 + intended lat_mse
+        from climate_learn.metrics.utils import MetricsMetaInfo
+        hy_ = (721 if (h, w) == (128, 256) else 4 * h)
+        meta = MetricsMetaInfo(in_vars, OUT_VARS, np.linspace(-90.0, 90.0, hy_), None, None)
+        loss_fn = cl.load_loss(dev, None, a.daymet_loss, True, meta)
     eng.train()
 
     # synthetic ERA5-shaped batch, resident in HBM before the timed region (SURVEY 8d input recipe)
@@ -464,12 +472,12 @@ def main():
                                    "loss-scaled fused AdamW; dropout %.1f, drop-path %.1f"
                                    % (a.model, "Daymet-like multi-variable" if a.daymet else "ERA5 1.40625deg->0.25deg",
                                       B, V, h, w, B, C, 4 * h, 4 * w, hy, wy,
-                                      "perceptual (L1 + 0.5 LPIPS-VGG16)" if a.daymet else "bayesian_tv", drop, drop),
+                                      (a.daymet_loss + " (L1 + 0.5 LPIPS-VGG16" + (" + lat-weighted MSE)" if "lat" in a.daymet_loss else ")")) if a.daymet else "bayesian_tv", drop, drop),
                        "per_gpu_batch": B, "global_batch": B * dp_world, "tokens_per_sample": L, "params": nparams,
                        "parallelism": (("fsdp%d" if a.fsdp else "dp%d") % world) if tp == 1 else "dp%dxtp%d" % (dp_world, tp),
                        "activation_recompute": bool(a.recompute),
                        "hipgraph": bool(a.graph),
-                       "loss": "perceptual" if a.daymet else "bayesian_tv", "in_vars": V},
+                       "loss": a.daymet_loss if a.daymet else "bayesian_tv", "in_vars": V},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_split": split,
                          "algorithmic_bytes_per_launch": gm.get("bytes", None),

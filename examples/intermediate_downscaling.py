@@ -168,15 +168,21 @@ def main():
             # parallelism.fsdp > 1 asks the reference for sharded FSDP (:609-617): FULL_SHARD over the data-parallel ranks, or
             # HYBRID_SHARD (shards of `fsdp` ranks, replicated `simple_ddp` times) -> the parameter-sharding engine.
             # `parallelism.shard_strategy: grad_op` keeps the parameters replicated and shards gradients + optimizer state only
-            # (the SHARD_GRAD_OP-like mode of the NO_SHARD engine); tensor parallelism combines with that mode only.
+            # (the SHARD_GRAD_OP-like mode of the NO_SHARD engine).  Both combine with tensor parallelism: the reference's
+            # 2-D layout (configs/interm_1b.yaml:14-24, fsdp x simple_ddp x tensor_par) shards every tensor-parallel column
+            # over its own data-parallel ranks.
             shard = fsdp_size > 1 and dp_size > 1
-            full = shard and par.get("shard_strategy", "full") == "full" and tp == 1
+            strategy = par.get("shard_strategy", "full")
+            if strategy not in ("full", "grad_op"):
+                raise ValueError("parallelism.shard_strategy must be 'full' or 'grad_op', got %r" % (strategy,))
+            full = shard and strategy == "full"
             if full:
                 hybrid = ddp_size > 1
                 print("enter hybrid FSDP," if hybrid else "enter fully sharded FSDP,", flush=True)
                 eng = cl.HipFullyShardedDataParallel(
                     model, process_group=init_par_groups.fsdp_group if hybrid else dp_group, unit_types=(Block, nn.Sequential),
-                    sync_module_states=True, replicate_group=init_par_groups.simple_ddp_group if hybrid else None)
+                    sync_module_states=True, replicate_group=init_par_groups.simple_ddp_group if hybrid else None,
+                    tp_group=tp_group)
                 if world_rank == 0:
                     print("per-rank parameter bytes:", eng.param_bytes_per_rank(), flush=True)
             else:
@@ -207,6 +213,9 @@ def main():
         capturable = world_size == 1 or dist.get_backend() == "nccl"      # gloo rehearsals stage through the host: no capture
         capturable = capturable and getattr(train_loss, "graph_capturable", True)
         capturable = capturable and not getattr(eng, "shard_params", False)    # gathers / releases are host-driven
+        if hg is True and (tp > 1 or getattr(eng, "shard_params", False) or not capturable):
+            raise ValueError("trainer.hipgraph: true is not available here (tensor parallelism, the parameter-sharding engine, a "
+                             "gloo rehearsal or a loss that reads the host): use 'auto' or false")     # never a silent fallback
         use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable)) and tp == 1
         gstep, gshape = None, None
         for epoch in range(epoch_start, max_epochs):

@@ -202,15 +202,18 @@ int orbit2_maxpool2_bwd(const void* g, const void* x, const void* tapg, void* dz
  * w1: fp32 [(t*3 + ci)][64], b1: fp32 [64]; out: [N][H][W][64] bf16 */
 int orbit2_lpips_conv1_fwd(const float* img, const float* w1, const float* b1, void* out, int N, int H, int W,
                            void* stream);
-/* dimg (NCHW fp32) = conv1 input gradient / scale + l1_coef * sign(pred - target)   (the L1 term of the loss) */
+/* dimg (NCHW fp32) = conv1 input gradient / scale + l1_coef * gscale[0] * sign(pred - target)   (the L1 term of the loss).
+ * gscale (here and in orbit2_lpips_tap_bwd): device pointer to the scalar upstream gradient of the loss (loss scale included)
+ * or NULL for 1 -- the backward never reads it on the host, so the loss can be captured in a hipGraph. */
 int orbit2_lpips_conv1_bwd(const void* dz, const float* w1, const float* pred, const float* target, float l1_coef,
-                           float* dimg, int N, int H, int W, void* stream);
+                           const float* gscale, float* dimg, int N, int H, int W, void* stream);
 /* LPIPS head of one tap.  feats: [2B][HW][C] bf16, images 0..B-1 = prediction, B..2B-1 = target; lin: fp32 [C].
  * fwd: val[b] += mean_px sum_c lin_c (f0_c/(|f0|+1e-10) - f1_c/(|f1|+1e-10))^2.   C in {64,128,256,512}.
- * bwd: gout[b][px][c] = coef * d(sum_c ...)/d f0_c * (f0_c > 0)  -- the gradient w.r.t. the tap's PRE-ReLU output
+ * bwd: gout[b][px][c] = coef * gscale[0] * d(sum_c ...)/d f0_c * (f0_c > 0)  -- the gradient w.r.t. the tap's PRE-ReLU output
  * (bf16; a pixel whose prediction features are all zero gets 0 where autograd of sqrt at 0 would produce NaN) */
 int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, void* stream);
-int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, int B, int HW, int C, void* stream);
+int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, const float* gscale, int B, int HW, int C,
+                         void* stream);
 /* out[0] += mean |a - b|   (F.l1_loss, metrics/functional.py:30) */
 int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, void* stream);
 

@@ -492,6 +492,9 @@ def training_loss(sd, cfg, x, y, in_variables, out_variables, loss_name="bayesia
         return perceptual(yhat, tgt, lpips_sd)
     if loss_name == "lat_mse":
         return mse(yhat, tgt, out_variables, var_weights or {}, True, lat_weights(lat, yhat.shape[2]))
+    if loss_name == "perceptual_lat_mse":       # BASELINE configs[4]: perceptual + intended lat_mse
+        return perceptual(yhat, tgt, lpips_sd) + mse(yhat, tgt, out_variables, var_weights or {}, True,
+                                                     lat_weights(lat, yhat.shape[2]))
     return LOSSES[loss_name](yhat, tgt, out_variables, var_weights or {}, True)
 
 

@@ -489,11 +489,12 @@ def lpips_conv1_fwd(img, w1, b1):
     return out
 
 
-def lpips_conv1_bwd(dz, w1, pred, target, l1_coef):
+def lpips_conv1_bwd(dz, w1, pred, target, l1_coef, gscale=None):
     _dev(dz, BF, "dz"); _dev(pred, F32, "pred"); _dev(target, F32, "target")
     N, _, H, W = pred.shape
     dimg = torch.empty_like(pred)
-    _chk(lib().orbit2_lpips_conv1_bwd(_p(dz), _p(w1), _p(pred), _p(target), C.c_float(l1_coef), _p(dimg), N, H, W,
+    gs = None if gscale is None else _p(_dev(gscale, F32, "gscale"))
+    _chk(lib().orbit2_lpips_conv1_bwd(_p(dz), _p(w1), _p(pred), _p(target), C.c_float(l1_coef), gs, _p(dimg), N, H, W,
                                       _stream()), "orbit2_lpips_conv1_bwd")
     return dimg
 
@@ -503,10 +504,11 @@ def lpips_tap_fwd(feats, lin, val, B, HW, Cc):
     _chk(lib().orbit2_lpips_tap_fwd(_p(feats), _p(lin), _p(val), B, HW, Cc, _stream()), "orbit2_lpips_tap_fwd")
 
 
-def lpips_tap_bwd(feats, lin, coef, B, HW, Cc):
+def lpips_tap_bwd(feats, lin, coef, B, HW, Cc, gscale=None):
     _dev(feats, BF, "feats"); _dev(lin, F32, "lin")
     g = torch.empty(B * HW, Cc, dtype=BF, device=feats.device)
-    _chk(lib().orbit2_lpips_tap_bwd(_p(feats), _p(lin), _p(g), C.c_float(coef), B, HW, Cc, _stream()),
+    gs = None if gscale is None else _p(_dev(gscale, F32, "gscale"))
+    _chk(lib().orbit2_lpips_tap_bwd(_p(feats), _p(lin), _p(g), C.c_float(coef), gs, B, HW, Cc, _stream()),
          "orbit2_lpips_tap_bwd")
     return g
 

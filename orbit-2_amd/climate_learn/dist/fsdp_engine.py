@@ -48,16 +48,28 @@ class _Unit(Bucket):
         self.pevent = None         # communication-stream event: gather done
         self.gbuf = None           # index of the pooled gradient buffer
         self.launched = False
+        self.gaps: List[Tuple[int, int]] = []      # [start, end) ranges of the unit's range no backward kernel writes
+        self.layout = ()           # signature of the member layout: units with equal signatures write the same ranges
 
 
 class HipFullyShardedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (), is_lowp=None,
-                 sync_module_states: bool = True, replicate_group=None, prefetch: bool = True, pool_size: int = 3):
+                 sync_module_states: bool = True, replicate_group=None, prefetch: bool = True, pool_size: int = 3,
+                 tp_group=None):
         """process_group: the SHARD group (all data-parallel ranks for FULL_SHARD, the reference's fsdp_group for HYBRID);
-        replicate_group: the group of ranks holding the same chunk (the reference's simple_ddp_group; HYBRID only)."""
+        replicate_group: the group of ranks holding the same chunk (the reference's simple_ddp_group; HYBRID only);
+        tp_group: this rank's tensor-parallel group (dist/tp.py; the reference's 2-D FSDP x TP layout, configs/interm_1b.yaml:
+        14-24).  The model then holds the rank's head / column slices; the shard and replicate groups are the data-parallel
+        ranks of ONE tensor-parallel column, so chunks are cut from the rank's own slices and the tensor-parallel collectives of
+        the model are untouched.  Parameters that are NOT split over tp_group (LayerNorms, embeddings, convolutions) are
+        replicas: laid out first inside every unit, their reduced gradients are overwritten with the group's first rank's
+        (as HipDataParallel does: atomics-ordered sums differ by an ulp, AdamW would turn that into +-lr)."""
         super().__init__()
         self.module = module
         self.pg = process_group
+        self.tp_group = tp_group if (tp_group is not None and dist.is_initialized()
+                                     and dist.get_world_size(tp_group) > 1) else None
+        self._replicas_synced = False
         self.rg = replicate_group if (replicate_group is not None and dist.get_world_size(replicate_group) > 1) else None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -96,11 +108,17 @@ class HipFullyShardedDataParallel(nn.Module):
             u = _Unit(uname)
             lo = [(n, p) for n, p in ps if is_lowp(n, p)]
             hi = [(n, p) for n, p in ps if not is_lowp(n, p)]
+            if self.tp_group is not None:           # replicas first, tensor-parallel slices after (stable order)
+                lo.sort(key=lambda np_: hasattr(np_[1], "_o2_tp"))
+                hi.sort(key=lambda np_: hasattr(np_[1], "_o2_tp"))
             u.sharded = bool(lo) and uname != "root"
             off = 0
+            u.rep_lo = 0                            # length of the replicated prefix of the unit's bf16 range
             for n, p in lo:
                 u.members.append((p, off, p.numel()))
                 off += _round_up(p.numel())
+                if not hasattr(p, "_o2_tp"):
+                    u.rep_lo = off
             u.n = _round_up(off, N * _ALIGN) if lo else 0
             u.ck = u.n // N
             if u.sharded:
@@ -171,9 +189,12 @@ class HipFullyShardedDataParallel(nn.Module):
                                               p16=self.flat16[s16 + c0:s16 + c0 + u.ck]))
                 self.opt_state_size += u.ck
             hi_members, s32h, sg = [], o32, og32
+            rep_hi = 0
             for n, p in hi:
                 k = p.numel()
                 hi_members.append((p, og32 - sg, k))
+                if not hasattr(p, "_o2_tp"):
+                    rep_hi = og32 - sg + _round_up(k)
                 self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
                 p.data = self.flat32[o32:o32 + k].view(p.shape)
                 p.grad = self.g32[og32:og32 + k].view(p.shape)
@@ -183,6 +204,17 @@ class HipFullyShardedDataParallel(nn.Module):
                     p.register_post_accumulate_grad_hook(self._hi_hook)
                 o32 += _round_up(k)
                 og32 += _round_up(k)
+            # gradient ranges of the tensor-parallel replicas on THIS rank (finish_grad_sync broadcasts them)
+            u.rep_views = []
+            if self.tp_group is not None:
+                if u.sharded:
+                    a, b = max(0, self.rank * u.ck), min(u.rep_lo, (self.rank + 1) * u.ck)
+                    if a < b:
+                        u.rep_views.append(self.gchunk16[u.cs + a - self.rank * u.ck:u.cs + b - self.rank * u.ck])
+                elif lo and u.rep_lo:
+                    u.rep_views.append(self.g16[u.res16:u.res16 + u.rep_lo])
+                if rep_hi:
+                    u.rep_views.append(self.g32[sg:sg + rep_hi])
             if hi:
                 u.grad_views.append(self.g32[sg:og32])
                 self.opt_segments.append(dict(kind="hi", n=og32 - sg, os=self.opt_state_size, gather=False, members=hi_members,
@@ -191,8 +223,29 @@ class HipFullyShardedDataParallel(nn.Module):
             self.units.append(u)
         self.sharded_units = [u for u in self.units if u.sharded]
         # pools: gathered bf16 parameters (pool_size buffers) and per-unit gradient staging (2 buffers)
-        self.ppool = [torch.empty(max(max_n, 1), dtype=BF, device=dev) for _ in range(pool_size)]
-        self.gpool = [torch.empty(max(max_n, 1), dtype=BF, device=dev) for _ in range(2)]
+        # The pooled buffers start ZEROED and the ranges of a unit that no kernel writes (alignment padding between members and
+        # up to world * 128, members with requires_grad = False) are re-zeroed whenever a buffer passes to a unit of another
+        # layout (pre_backward): whatever sits there is reduce-scattered into gchunk16, seen by the scaler's finite check and
+        # applied by AdamW, so it must never be allocator garbage (a non-finite pattern would skip every step and decay the loss
+        # scale to its floor).
+        self.ppool = [torch.zeros(max(max_n, 1), dtype=BF, device=dev) for _ in range(pool_size)]
+        self.gpool = [torch.zeros(max(max_n, 1), dtype=BF, device=dev) for _ in range(2)]
+        self._glayout = [None, None]                   # layout signature of the unit that last wrote each gradient buffer
+        for u in self.sharded_units:
+            pos, gaps = 0, []
+            for p_, off, k in u.members:
+                if off > pos:
+                    gaps.append((pos, off))
+                if p_.requires_grad:
+                    pos = off + k
+                else:
+                    pos = off                              # a frozen member is a gap: nothing writes its gradient
+                    gaps.append((off, off + k))
+                    pos = off + k
+            if pos < u.n:
+                gaps.append((pos, u.n))
+            u.gaps = gaps
+            u.layout = tuple((off, k, bool(p_.requires_grad)) for p_, off, k in u.members)
         self._pfree = list(range(pool_size))
         self._gfree = [0, 1]
         self._pfree_ev = [None] * pool_size            # compute-stream events: last kernel using the buffer has been queued
@@ -314,6 +367,10 @@ class HipFullyShardedDataParallel(nn.Module):
             if self.comm_stream is not None and self._gfree_ev[g] is not None:
                 torch.cuda.current_stream().wait_event(self._gfree_ev[g])      # its last reduce-scatter has finished
             buf = self.gpool[g]
+            if self._glayout[g] != u.layout:              # another layout wrote here last: its members overlap this unit's gaps
+                for a, b in u.gaps:
+                    buf[a:b].zero_()
+                self._glayout[g] = u.layout
             for p, off, k in u.members:
                 p._o2g = buf[off:off + k].view(p.shape)
                 p._o2_fresh = True
@@ -328,6 +385,7 @@ class HipFullyShardedDataParallel(nn.Module):
     # ---- gradient life cycle -----------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
         self.g32.zero_()
+        self._replicas_synced = False
         for u in self.units:
             u.pending = sum(1 for p in u.params if p.requires_grad)
             u.handle = None
@@ -421,6 +479,12 @@ class HipFullyShardedDataParallel(nn.Module):
             self._release(u)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.tp_group is not None and not self._replicas_synced:
+            from . import tp as _tp
+            for u in self.units:
+                for v in u.rep_views:
+                    _tp.broadcast_first(v, self.tp_group)
+            self._replicas_synced = True
 
     def gather_params(self):
         """after the local AdamW: the resident (root) unit's compute copies are re-assembled from the ranks' chunks; sharded
@@ -466,6 +530,11 @@ class HipFullyShardedDataParallel(nn.Module):
         if strict and missing:
             raise RuntimeError("missing keys in state_dict: %s" % missing[:5])
         r = self.module.load_state_dict(rest, strict=False)
+        if strict:      # nn.Module semantics for the resident keys too (the sharded names are absent from `rest` on purpose)
+            miss = [k_ for k_ in r.missing_keys if k_ not in sharded_names]
+            if miss or r.unexpected_keys:
+                raise RuntimeError("Error(s) in loading state_dict: missing keys %s, unexpected keys %s"
+                                   % (miss[:5], list(r.unexpected_keys)[:5]))
         for u in self.sharded_units:
             full = torch.zeros(u.n, dtype=F32, device=self.device)
             cur = self.gather_range(self.chunk32[u.cs:u.cs + u.ck]) if missing else None

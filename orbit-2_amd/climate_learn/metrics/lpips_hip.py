@@ -149,14 +149,16 @@ class _PerceptualFn(torch.autograd.Function):
         net, acts, taps = ctx.net, ctx.acts, ctx.taps
         B, H, W = ctx.dims
         p32, t32 = ctx.saved_tensors
-        go = float(gout)                                  # scalar upstream gradient (loss scale included)
+        # the scalar upstream gradient (loss scale included) stays ON THE DEVICE: the tap / first-conv kernels read it through
+        # a pointer, so the backward has no host read (no pipeline stall, capturable in a hipGraph)
+        go = gout.detach().reshape(1).to(F32).contiguous()
 
         def tap(j):
             """gradient of 0.5*mean_b(val) w.r.t. the pre-ReLU output of stage j (prediction half), or None"""
             if j not in taps:
                 return None
             _, f, h, w, c = acts[j]
-            return _hip.lpips_tap_bwd(f, net.lins[taps[j]], go * 0.5 / (B * h * w), B, h * w, c)
+            return _hip.lpips_tap_bwd(f, net.lins[taps[j]], 0.5 / (B * h * w), B, h * w, c, gscale=go)
 
         def pred_half(j):
             _, f, h, w, c = acts[j]
@@ -182,5 +184,5 @@ class _PerceptualFn(torch.autograd.Function):
                 gz = _hip.maxpool2_bwd(gp, pred_half(j - 2), B, sh, sw, sc, tapg=tap(j - 2))
                 j -= 2
             del dcol
-        dimg = _hip.lpips_conv1_bwd(gz, net.w1, p32, t32, go / p32.numel())
+        dimg = _hip.lpips_conv1_bwd(gz, net.w1, p32, t32, 1.0 / p32.numel(), gscale=go)
         return dimg, None, None

@@ -71,7 +71,7 @@ class PERCEPTUAL(Metric):
     Export the real ones on a machine that has the packages:
         import lpips, torch; torch.save(lpips.LPIPS(net='vgg').state_dict(), 'lpips_vgg.pt')"""
 
-    graph_capturable = False      # its backward reads the upstream gradient on the host: no hipGraph capture of this loss
+    graph_capturable = True       # the backward keeps the upstream scalar on the device (lpips_hip._PerceptualFn.backward)
 
     def __init__(self, device, model, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None,
                  synthetic_weights: Optional[bool] = None):
@@ -96,6 +96,27 @@ class PERCEPTUAL(Metric):
     def __call__(self, pred, target, var_names: Optional[List[str]] = None,
                  var_weights: Optional[Dict[str, float]] = None):
         return self.loss_fn.perceptual(pred, target)
+
+
+@register("perceptual_lat_mse")
+class PerceptualLatMSE(PERCEPTUAL, LatitudeWeightedMetric):
+    """BASELINE.json configs[4] names a "hybrid perceptual + lat-weighted MSE loss" (SURVEY 8d-5): the sum of the reference's
+    `perceptual` (metrics.py:119-187: L1 + 0.5 * mean LPIPS-VGG16) and its intended `lat_mse` (metrics.py:295-316: the
+    variable- and latitude-weighted MSE, aggregate over channels).  The reference has no object for the sum; this one takes
+    the perceptual loss's constructor (device, model, ...) and training_step's keyword arguments."""
+
+    def __init__(self, device, model, aggregate_only: bool = False, metainfo: Optional[MetricsMetaInfo] = None,
+                 synthetic_weights: Optional[bool] = None):
+        PERCEPTUAL.__init__(self, device, model, aggregate_only, metainfo, synthetic_weights)
+        w = np.cos(np.deg2rad(np.asarray(self.metainfo.lat, dtype=np.float64)))
+        self.lat_weights = torch.from_numpy(w / w.mean()).float().view(1, 1, -1, 1)
+
+    def __call__(self, pred, target, var_names: Optional[List[str]] = None,
+                 var_weights: Optional[Dict[str, float]] = None):
+        self.cast_to_device(pred)
+        per = self.loss_fn.perceptual(pred, target)
+        lat = mse(pred, target, var_names, var_weights, True, self.lat_weights)
+        return per + lat
 
 
 @register("rmse")

@@ -40,7 +40,7 @@ def load_loss(device, model, loss_name, aggregate_only, metainfo):
     cls = METRICS_REGISTRY.get(loss_name)
     if cls is None:
         raise NotImplementedError(_issue("loss", loss_name))
-    if loss_name == "perceptual":      # reference loaders.py:439-441: this one loss takes (device, model)
+    if loss_name in ("perceptual", "perceptual_lat_mse"):      # reference loaders.py:439-441: this loss takes (device, model)
         return cls(device, model, aggregate_only=aggregate_only, metainfo=metainfo)
     return cls(aggregate_only=aggregate_only, metainfo=metainfo)
 

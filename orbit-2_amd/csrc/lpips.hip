@@ -188,8 +188,10 @@ __global__ __launch_bounds__(256) void lpips_conv1_fwd_kernel(const float* __res
 // dimg[n][ci][y][x] = (1/scale_ci) * sum_t sum_co dz[p - off_t][co] * w1[t][ci][co]  +  l1_coef * sign(pred - target)
 __global__ __launch_bounds__(256) void lpips_conv1_bwd_kernel(const bf16_t* __restrict__ dz, const float* __restrict__ w1,
                                                               const float* __restrict__ pred,
-                                                              const float* __restrict__ target, float l1_coef,
+                                                              const float* __restrict__ target, float l1_coef_arg,
+                                                              const float* __restrict__ gscale,
                                                               float* __restrict__ dimg, int N, int H, int W) {
+  const float l1_coef = gscale ? l1_coef_arg * gscale[0] : l1_coef_arg;     // upstream scalar gradient stays on the device
   __shared__ float sw[27 * 64];
   for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[i] = w1[i];
   __syncthreads();
@@ -227,8 +229,9 @@ __global__ __launch_bounds__(256) void lpips_conv1_bwd_kernel(const bf16_t* __re
 // f: [2B][HW][C] (images 0..B-1 = prediction, B..2B-1 = target); one group of C/8 lanes per pixel.
 template <int G, bool BWD>
 __global__ __launch_bounds__(256) void lpips_tap_kernel(const bf16_t* __restrict__ f, const float* __restrict__ lin,
-                                                        float* __restrict__ val, bf16_t* __restrict__ gout, float coef,
-                                                        int B, int HW) {
+                                                        float* __restrict__ val, bf16_t* __restrict__ gout, float coef_arg,
+                                                        const float* __restrict__ gscale, int B, int HW) {
+  const float coef = (BWD && gscale) ? coef_arg * gscale[0] : coef_arg;       // upstream scalar gradient stays on the device
   constexpr int C = G * 8;
   __shared__ float red[256 / 64];
   const int b = blockIdx.y;
@@ -344,23 +347,23 @@ extern "C" int orbit2_lpips_conv1_fwd(const float* img, const float* w1, const f
 }
 
 extern "C" int orbit2_lpips_conv1_bwd(const void* dz, const float* w1, const float* pred, const float* target,
-                                      float l1_coef, float* dimg, int N, int H, int W, void* stream) {
+                                      float l1_coef, const float* gscale, float* dimg, int N, int H, int W, void* stream) {
   if (!dz || !w1 || !pred || !target || !dimg || N <= 0 || H <= 0 || W <= 0) return O2_ERR_ARG;
   hipLaunchKernelGGL(lpips_conv1_bwd_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dz, w1, pred, target, l1_coef, dimg, N, H, W);
+                     (const bf16_t*)dz, w1, pred, target, l1_coef, gscale, dimg, N, H, W);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
 
 template <bool BWD>
-static int lpips_tap_launch(const void* f, const float* lin, float* val, void* gout, float coef, int B, int HW, int C,
-                            hipStream_t s) {
+static int lpips_tap_launch(const void* f, const float* lin, float* val, void* gout, float coef, const float* gscale, int B,
+                            int HW, int C, hipStream_t s) {
   int blocks = (HW * (C / 8) + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   dim3 grid((unsigned)blocks, (unsigned)B), block(256);
 #define O2_TAP(G)                                                                                               \
   hipLaunchKernelGGL((lpips_tap_kernel<G, BWD>), grid, block, 0, s, (const bf16_t*)f, lin, val, (bf16_t*)gout, \
-                     coef, B, HW)
+                     coef, gscale, B, HW)
   switch (C) {
     case 64: O2_TAP(8); break;
     case 128: O2_TAP(16); break;
@@ -375,13 +378,13 @@ static int lpips_tap_launch(const void* f, const float* lin, float* val, void* g
 
 extern "C" int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, void* stream) {
   if (!feats || !lin || !val || B <= 0 || HW <= 0) return O2_ERR_ARG;
-  return lpips_tap_launch<false>(feats, lin, val, nullptr, 0.f, B, HW, C, (hipStream_t)stream);
+  return lpips_tap_launch<false>(feats, lin, val, nullptr, 0.f, nullptr, B, HW, C, (hipStream_t)stream);
 }
 
-extern "C" int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, int B, int HW, int C,
-                                    void* stream) {
+extern "C" int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, const float* gscale, int B,
+                                    int HW, int C, void* stream) {
   if (!feats || !lin || !gout || B <= 0 || HW <= 0) return O2_ERR_ARG;
-  return lpips_tap_launch<true>(feats, lin, nullptr, gout, coef, B, HW, C, (hipStream_t)stream);
+  return lpips_tap_launch<true>(feats, lin, nullptr, gout, coef, gscale, B, HW, C, (hipStream_t)stream);
 }
 
 extern "C" int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, void* stream) {

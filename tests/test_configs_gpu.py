@@ -139,3 +139,84 @@ def test_interm_10b_training_step_with_recompute():
         y2 = eng(x2, ERA5_VARS, OUT_VARS)
         y1 = eng(x2[1:2].contiguous(), ERA5_VARS, OUT_VARS)
     assert y2.shape == (2, 3, 512, 1024) and torch.isfinite(y2).all() and torch.equal(y2[1:2], y1)
+
+
+def test_interm_1b_daymet_like_hybrid_perceptual_step(monkeypatch):
+    """BASELINE configs[4] AT ITS SIZE: interm_1b (D3072 / 24 heads of 128 / depth 8), 7 Daymet-like inputs ->
+    3 outputs, the 96x192 -> 384x768 tile (L = 4608), hybrid loss `perceptual_lat_mse` = reference `perceptual`
+    (metrics.py:119-187, functional.py:17-33) + intended `lat_mse` (metrics.py:295-316), var weights {1,10,10}
+    (configs/interm_1b.yaml:225-232), train mode, loss-scaled AdamW.  The whole oracle cannot run at this width; checked:
+    finite step with finite non-zero gradients in every unit, seed determinism (same seeds -> same loss and gradients bit for
+    bit, new seeds -> different), the loss's LPIPS + L1 + lat-MSE value of the step's own predictions against the CPU oracle
+    (the VGG stack fits the CPU at 384x768), and batch independence of the eval prediction."""
+    import climate_learn as cl
+    from climate_learn import _ops
+    from climate_learn.metrics.lpips_hip import LPIPSVGG16
+    from climate_learn.metrics.utils import MetricsMetaInfo
+    from climate_learn.models.hub import Res_Slim_ViT
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import clip_replace_constant, training_step
+    from oracle import orbit2_oracle as O
+    monkeypatch.delenv("ORBIT2_LPIPS_WEIGHTS", raising=False)
+    monkeypatch.setenv("ORBIT2_LPIPS_SYNTHETIC", "1")
+    dev = torch.device("cuda")
+    h, w, B = 96, 192, 2
+    in_vars = CONST + OUT_VARS
+    with torch.device(dev):
+        model = Res_Slim_ViT(in_vars, (h, w), 7, 3, 1, superres_mag=4, cnn_ratio=4, patch_size=2, drop_path=0.1,
+                             drop_rate=0.1, learn_pos_emb=True, embed_dim=3072, depth=8, decoder_depth=4, num_heads=24,
+                             mlp_ratio=4, FusedAttn_option=cl.FusedAttn.HIP)
+    model.data_config(16.0, (h, w), 7, 3)
+    eng = cl.HipDataParallel(model, unit_types=(Block, nn.Sequential))
+    opt = cl.load_optimizer(eng, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+    scaler = cl.HipGradScaler(init_scale=8192.0, growth_interval=100, min_scale=128.0)
+    lat = np.linspace(25.0, 50.0, 4 * h)
+    loss_fn = cl.load_loss(dev, None, "perceptual_lat_mse", True, MetricsMetaInfo(in_vars, OUT_VARS, lat, None, None))
+    sd_l = {k: (v.to(torch.bfloat16).float() if "lin" not in k else v) for k, v in O.init_lpips_weights(5).items()}
+    loss_fn.loss_fn = LPIPSVGG16(dev, sd_l)                  # the same stand-in LPIPS weights as the oracle below
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 7, h, w, generator=g)
+    y = torch.randn(B, 3, 4 * h, 4 * w, generator=g)
+    y[:, 0] = torch.log1p(torch.relu(y[:, 0]))
+    batch = (x.to(dev), y.to(dev), in_vars, OUT_VARS)
+    eng.train()
+    cl.manual_seed(0)
+
+    def one(mark=None):
+        if mark is not None:
+            _ops.seeds.reset(mark)
+        loss = training_step(batch, 0, eng, dev, VW, loss_fn)
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        eng.finish_grad_sync()
+        return loss
+
+    mark = _ops.seeds.mark()
+    l1 = one()
+    assert torch.isfinite(l1) and 0.0 < float(l1) < 1e3
+    for bk in eng.buckets:
+        for v in bk.grad_views:
+            assert torch.isfinite(v.float()).all() and float(v.float().abs().sum()) > 0, bk.name
+    g1 = model.blocks[7].attn.qkv.weight._o2g.clone()
+    gh = model.head[8].weight._o2g.clone()
+    l2 = one(mark)                                           # same seeds: bit-identical
+    assert float(l2) == float(l1) and torch.equal(model.blocks[7].attn.qkv.weight._o2g, g1) and torch.equal(model.head[8].weight._o2g, gh)
+    l3 = one()                                               # fresh dropout / DropPath masks
+    assert float(l3) != float(l1) and not torch.equal(model.blocks[7].attn.qkv.weight._o2g, g1)
+    scaler.step(opt)
+    assert scaler.update() is False
+    # the loss object on the step's own predictions against the oracle (CPU, fp32): L1 + 0.5 LPIPS + lat-weighted MSE
+    eng.eval()
+    with torch.no_grad():
+        pred = eng(batch[0], in_vars, OUT_VARS)
+        yhat = clip_replace_constant(batch[1], pred, OUT_VARS)
+        val = loss_fn(yhat, batch[1], var_names=OUT_VARS, var_weights=VW)
+        p1 = eng(batch[0][1:2].contiguous(), in_vars, OUT_VARS)
+    assert pred.shape == (B, 3, 4 * h, 4 * w) and torch.equal(pred[1:2], p1)         # batch independence
+    yc, tc = yhat.float().cpu(), batch[1].float().cpu()
+    lp = float(O.lpips_vgg(yc, tc, sd_l).mean())
+    ref = float((yc - tc).abs().mean()) + 0.5 * lp + float(O.mse(yc, tc, OUT_VARS, VW, True, O.lat_weights(lat, 4 * h)))
+    assert abs(float(val) - ref) / ref < 1e-2, (float(val), ref)
+    per = float(loss_fn.loss_fn.perceptual(yhat, batch[1]))
+    lp_hip = 2.0 * (per - float((yc - tc).abs().mean()))
+    assert abs(lp_hip - lp) / lp < 3e-2, (lp_hip, lp)          # the LPIPS term alone (13 bf16 layers deep)

@@ -446,3 +446,155 @@ def test_fully_sharded_engine_world2_gloo():
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _simulate_unit_backward(fs, m_fs, rank, pr=None, rep=None):
+    """what the backward kernels do, on CPU: every sharded unit's members get rank-dependent gradients written into p._o2g
+    and report grad_ready (optionally mirrored into a replicated engine's parameters `pr` for comparison)"""
+    for u in reversed(fs.sharded_units):
+        mod = m_fs.get_submodule(u.name)
+        fs.pre_backward(mod)
+        lowp = [(n, p) for n, p in mod.named_parameters() if getattr(p, "_o2_sharded", False) and p.requires_grad]
+        for n, p in lowp:
+            val = (torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) % 13 + rank + 1).to(torch.bfloat16)
+            p._o2g.copy_(val)
+            p._o2_fresh = False
+            if pr is not None:
+                q_ = pr[u.name + "." + n]
+                q_._o2g.copy_(val)
+                q_._o2_fresh = False
+        for n, p in lowp:
+            fs.grad_ready(p)
+            if rep is not None:
+                rep.grad_ready(pr[u.name + "." + n])
+        fs.post_backward(mod)
+
+
+def test_fully_sharded_engine_pool_padding_is_never_garbage():
+    """round-2 advisor finding: the pooled gradient buffers' alignment padding (head unit: 192-element bias padded to 256) and
+    the ranges of frozen members are never written by a kernel but ARE reduce-scattered, finite-checked and stepped by AdamW.
+    Poison the pools with NaN after construction (what an unlucky allocator hands out): every chunk must stay finite and the
+    padding zero -- also when a buffer passes from a Block to the differently laid out head and back."""
+    import climate_learn as cl
+    from climate_learn.models.hub.components.vit_blocks import Block
+    torch.manual_seed(3)
+    m = _build()
+    m.blocks[1].mlp.fc2.bias.requires_grad_(False)        # a frozen low-precision member of a sharded unit
+    fs = cl.HipFullyShardedDataParallel(m, unit_types=(Block, nn.Sequential))
+    head = [u for u in fs.sharded_units if u.name == "head"][0]
+    assert sum(b - a for a, b in head.gaps) > 0            # the head really has padding in this model
+    for step in range(2):
+        for b in fs.gpool + fs.ppool:
+            if step == 0:
+                b.fill_(float("nan"))
+        fs._glayout = [None, None] if step == 0 else fs._glayout
+        fs.zero_grad()
+        _simulate_unit_backward(fs, m, rank=0)
+        fs.finish_grad_sync()
+        assert torch.isfinite(fs.gchunk16.float()).all(), "garbage reached the reduced gradient chunks (step %d)" % step
+        for u in fs.sharded_units:
+            mine = fs.gchunk16[u.cs:u.cs + u.ck]
+            for a, b in u.gaps:
+                assert float(mine[a:b].float().abs().sum()) == 0.0, (u.name, a, b)
+    frozen = [u for u in fs.sharded_units if u.name == "blocks.1"][0]
+    assert any(b - a == m.blocks[1].mlp.fc2.bias.numel() for a, b in frozen.gaps)
+    with pytest.raises(RuntimeError):                      # strict load: resident keys are checked like nn.Module does
+        sd = fs.state_dict()
+        sd.pop("norm.weight")
+        fs.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        sd = fs.state_dict()
+        sd["not.a.key"] = torch.zeros(1)
+        fs.load_state_dict(sd)
+
+
+def _worker_hybrid(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import climate_learn as cl
+        from climate_learn.models.hub.components.vit_blocks import Block
+        # the reference's layout (examples/intermediate_downscaling.py:203-262): fsdp ranks adjacent, simple_ddp ranks strided
+        fsdp, ddp = 2, 2
+        shard_groups = [dist.new_group(list(range(i * fsdp, (i + 1) * fsdp))) for i in range(ddp)]
+        rep_groups = [dist.new_group(list(range(j, world, fsdp))) for j in range(fsdp)]
+        sg, rg = shard_groups[rank // fsdp], rep_groups[rank % fsdp]
+        torch.manual_seed(100 + rank)                 # different init per rank: rank 0's weights must win on all four
+        m_rep = _build()
+        torch.manual_seed(100 + rank)
+        m_fs = _build()
+        rep = cl.HipDataParallel(m_rep, unit_types=(Block, nn.Sequential), overlap=False)          # NO_SHARD over all 4 ranks
+        fs = cl.HipFullyShardedDataParallel(m_fs, process_group=sg, replicate_group=rg, unit_types=(Block, nn.Sequential))
+        assert fs.world == 2 and fs.replicas == 2 and fs.grad_world == 4 and fs.rank == rank % fsdp
+        sums = [None] * world
+        dist.all_gather_object(sums, float(fs.chunk32.double().sum()))
+        assert sums[0] == sums[2] and sums[1] == sums[3]            # replicas hold identical chunks (rank 0's weights)
+        pr = dict(m_rep.named_parameters())
+        pf = dict(m_fs.named_parameters())
+        rep.zero_grad()
+        fs.zero_grad()
+        _simulate_unit_backward(fs, m_fs, rank, pr, rep)
+        for n, p in pf.items():                       # the resident rest: root unit + fp32-compute parameters
+            if getattr(p, "_o2_sharded", False) or not p.requires_grad:
+                continue
+            q_ = pr[n]
+            if hasattr(p, "_o2g") and p._o2g is not None:
+                p._o2g.fill_(float(rank + 1)); q_._o2g.fill_(float(rank + 1))
+                p._o2_fresh = q_._o2_fresh = False
+                fs.grad_ready(p); rep.grad_ready(q_)
+            else:
+                p.grad.add_(0.5 * (rank + 1)); q_.grad.add_(0.5 * (rank + 1))
+                fs._hi_hook(p); rep._hi_hook(q_)
+        fs.finish_grad_sync()
+        rep.finish_grad_sync()
+        # reduce-scatter over the shard group THEN all-reduce over the replica group == the sum over all four ranks
+        for u in fs.sharded_units:
+            mine = fs.gchunk16[u.cs:u.cs + u.ck]
+            for p, off, k in u.members:
+                lo, hi = max(off, fs.rank * u.ck), min(off + k, (fs.rank + 1) * u.ck)
+                if lo < hi:
+                    name = [n for n, pp in pf.items() if pp is p][0]
+                    ref = pr[name]._o2g.reshape(-1)[lo - off:hi - off]
+                    assert torch.equal(mine[lo - fs.rank * u.ck:hi - fs.rank * u.ck], ref), name
+        assert torch.equal(m_fs.conv_out.weight.grad, m_rep.conv_out.weight.grad)
+        assert torch.equal(m_fs.norm.weight._o2g, m_rep.norm.weight._o2g)
+        # a stand-in AdamW step on the chunks (same arithmetic on both engines), then the full dicts must agree everywhere
+        for sgm in fs.opt_segments:
+            sgm["p32"].sub_(1e-3 * sgm["g"].float() / fs.grad_world)
+            if sgm["p16"] is not None:
+                sgm["p16"].copy_(sgm["p32"])
+        for sgm in rep.opt_segments:
+            sgm["p32"].sub_(1e-3 * sgm["g"].float() / world)
+        fs.gather_params()
+        sd_f, sd_r = fs.state_dict(), rep.state_dict()
+        assert set(sd_f) == set(sd_r)
+        for k in sd_r:
+            assert torch.equal(sd_f[k], sd_r[k]), k     # every parameter bit-equal to the replicated engine's after the step
+        both = [None] * world
+        dist.all_gather_object(both, {k: float(v.double().sum()) for k, v in sd_f.items()})
+        assert all(b == both[0] for b in both)          # ... and identical on all four ranks (both replicas, both shards)
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_hybrid_shard_engine_world4_gloo():
+    """reference FSDP HYBRID_SHARD (examples/intermediate_downscaling.py:609-613; every large YAML is fsdp x simple_ddp):
+    2 shards x 2 replicas on four gloo ranks.  The reduce-scatter over the shard group followed by the all-reduce over the
+    replica group leaves the sum over ALL ranks in every chunk; after a step every parameter is bit-equal to the NO_SHARD
+    engine's over the same four ranks and identical on both replicas."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hybrid, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res

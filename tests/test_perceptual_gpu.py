@@ -149,3 +149,54 @@ def test_perceptual_metric_object_and_loader(hip, monkeypatch):
     assert float(same) == 0.0
     with pytest.raises(ValueError):
         loss(torch.zeros(1, 2, 32, 32).cuda(), torch.zeros(1, 2, 32, 32).cuda())
+
+
+def test_perceptual_lat_mse_matches_oracle_and_graph_capture(hip, monkeypatch):
+    """BASELINE configs[4] "hybrid perceptual + lat-weighted MSE"  = reference `perceptual` (metrics.py:119-187)
+    + intended `lat_mse` (metrics.py:295-316): registered as `perceptual_lat_mse`; value and gradient against the oracle's sum
+    (same seeded stand-in LPIPS weights on both sides).  The backward keeps the upstream scalar on the device, so the loss can be
+    captured in a hipGraph: replaying the captured forward + backward reproduces the eager gradient bit for bit."""
+    import numpy as np
+    import climate_learn as cl
+    from climate_learn.metrics.utils import MetricsMetaInfo
+    from climate_learn.metrics.lpips_hip import LPIPSVGG16
+    monkeypatch.delenv("ORBIT2_LPIPS_WEIGHTS", raising=False)
+    monkeypatch.setenv("ORBIT2_LPIPS_SYNTHETIC", "1")
+    B, H, W = 2, 32, 64
+    names = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+    vw = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0}
+    lat = np.linspace(-60.0, 70.0, H + 8)              # longer than the prediction: the weights are cropped to its rows
+    loss = cl.load_loss("cuda", None, "perceptual_lat_mse", True, MetricsMetaInfo(names, names, lat, None, None))
+    assert loss.graph_capturable
+    sd = {k: rt(v) for k, v in O.init_lpips_weights(5).items() if "lin" not in k}
+    sd.update({k: v for k, v in O.init_lpips_weights(5).items() if "lin" in k})
+    loss.loss_fn = LPIPSVGG16("cuda", sd)                # same stand-in weights as the oracle below
+    g = torch.Generator().manual_seed(11)
+    pred = torch.randn(B, 3, H, W, generator=g) * 0.6
+    target = pred * 0.7 + 0.5 * torch.randn(B, 3, H, W, generator=g)
+    pr = pred.clone().requires_grad_()
+    ref = O.perceptual(pr, target, sd) + O.mse(pr, target, names, vw, True, O.lat_weights(lat, H))
+    ref.backward()
+    pg = pred.cuda().requires_grad_()
+    v = loss(pg, target.cuda(), var_names=names, var_weights=vw)
+    (v * 2.0).backward()
+    assert v.dim() == 0 and abs(float(v) - float(ref)) / float(ref) < 5e-3
+    assert rel_l2(pg.grad.cpu() / 2.0, pr.grad) < 3e-2
+    # hipGraph capture of forward + backward (upstream scalar = a device tensor, as the loss scaler's scale is)
+    sp, st = pred.cuda().clone().requires_grad_(), target.cuda().clone()
+    scale = torch.full((), 2.0, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # warm-up outside the capture
+        (loss(sp, st, var_names=names, var_weights=vw) * scale).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    sp.grad = None
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        lv = loss(sp, st, var_names=names, var_weights=vw)
+        (lv * scale).backward()
+    scale.fill_(4.0)                                      # the replay reads the CURRENT scalar, on the device
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(sp.grad, pg.grad * 2.0, rtol=0, atol=0) or rel_l2(sp.grad, pg.grad * 2.0) < 1e-6
+    assert abs(float(lv) - float(v)) < 1e-6 * abs(float(v))
