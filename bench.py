@@ -41,8 +41,8 @@ MODELS = {  # configs/interm_*.yaml of the reference
     "interm_10b": dict(embed_dim=8192, depth=11, num_heads=32),
 }
 PEAK_BF16 = 2.5e15   # dense MFMA peak, MI355X_MICROARCH.md
-MALL_JSON = "r02_mall_latency.json"  # Infinity-Cache share of that traffic (TCC_EA0_RDREQ_LEVEL pass of tools/mall_probe.py)
-TRAFFIC_JSON = "r02_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
+MALL_JSON = "r03_mall_latency.json"  # Infinity-Cache share of that traffic (TCC_EA0_RDREQ_LEVEL pass of tools/mall_probe.py)
+TRAFFIC_JSON = "r03_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
 METRIC = "climate-grid samples/sec/node (fwd+bwd), interm_1b ERA5 1.4°→0.25°, 1/2/4/8 GPUs"
 
 
@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--daymet", action="store_true",
                     help="BASELINE configs[4] / SURVEY 8d-5: 7 Daymet-like inputs, 3 outputs, hybrid perceptual loss "
                          "(use --grid 96x192); not the headline configuration")
+    ap.add_argument("--mall-probe", action="store_true",
+                    help="run the memory-side latency calibration streams (orbit2_probe_read) before the steps: for the "
+                         "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum pass of tools/profile_round.sh")
     ap.add_argument("--daymet-loss", default="perceptual_lat_mse", choices=["perceptual_lat_mse", "perceptual"],
                     help="loss of the --daymet configuration: the hybrid perceptual + latitude-weighted MSE sum BASELINE "
                          "configs[4] names (default), or the reference's `perceptual` object alone")
@@ -268,6 +271,24 @@ def launch_check(a, rank, world, local):
                           "launch_check": True, "ranks_met": ranks, "backend": "gloo", "devices": devs}), flush=True)
 
 
+def _attn_roofline(prof, traffic_attn, note):
+    f, b = prof.get("attn_fwd"), prof.get("attn_bwd")
+    if not f or not b or not f["launches"]:
+        return None
+    work, ms, n = f["work"] + b["work"], f["ms"] + b["ms"], f["launches"] + b["launches"]
+    ach = work / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
+            "forward": {"achieved": f["work"] / f["ms"] / 1e9, "frac": f["work"] / f["ms"] / 1e9 / (PEAK_BF16 / 1e12),
+                        "avg_launch_ms": f["ms"] / f["launches"], "algorithmic_bytes_per_launch": f["bytes"]},
+            "backward": {"achieved": b["work"] / b["ms"] / 1e9, "frac": b["work"] / b["ms"] / 1e9 / (PEAK_BF16 / 1e12),
+                         "avg_launch_ms": b["ms"] / b["launches"], "algorithmic_bytes_per_launch": b["bytes"],
+                         "note": "one API launch = delta + dQ + fused dK/dV kernels; 7 matrix products executed for 4 credited"},
+            "traffic": traffic_attn, "traffic_note": note,
+            "algorithmic_bytes_per_launch": (f["bytes"] * f["launches"] + b["bytes"] * b["launches"]) / n,
+            "kernel": "orbit2_attn_fwd / orbit2_attn_bwd (csrc/attn.hip): every attention launch of the timed region",
+            "launches": n, "avg_launch_ms": ms / n}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -313,8 +334,11 @@ def main():
     drop = 0.0 if a.no_dropout else 0.1
     tp = a.tensor_par
     capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
-    capturable = capturable and not a.fsdp     # fsdp: host-driven gathers (the perceptual loss keeps its scalar on the device now)
-    a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable)
+    # (the parameter-sharding engine stays eager: capturing its cross-stream gather / release pattern was tried in round 3 and
+    #  hipStreamEndCapture crashes on it -- DESIGN 6c)
+    if a.fsdp and a.graph == "on":
+        raise SystemExit("--fsdp runs without hipGraph replay")
+    a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable and not a.fsdp)
     if tp > 1 and (world % tp or a.graph):
         raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)
     dp_world, dp_rank = world // tp, rank // tp
@@ -340,8 +364,6 @@ def main():
         blk.recompute = a.recompute
     nparams = sum(p.numel() for p in model.parameters())
     if a.fsdp:
-        if a.graph:
-            raise SystemExit("--fsdp runs without hipGraph replay")
         eng = cl.HipFullyShardedDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential), tp_group=tp_group)
     else:
         eng = cl.HipDataParallel(model, process_group=dp_group, unit_types=(Block, nn.Sequential),
@@ -383,9 +405,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.mall_probe:
+        _hip.mall_calibration()
     for i in range(a.warmup):
         step(i)
     fence()
+    if (world > 1 or force) and not a.graph:
+        eng.comm_stats = cl.CommStats()                 # HIP-event accounting of the collectives over the timed region
     if a.graph:
         # instrumented eager pass for the per-kernel (roofline) numbers, then the captured step for the throughput
         _hip.timer = _hip.KernelTimer()
@@ -439,26 +465,35 @@ def main():
         f_dense = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"])
         f_exec = forward_flops(L, V, m["embed_dim"], m["depth"], 4, C, h, w, m["num_heads"], folded_varagg=True)
         gm = prof.get("gemm_bf16", {"work": 0.0, "ms": 1.0, "launches": 0})
-        traffic = None     # HBM bytes per GEMM launch from the committed PMC passes of the same configuration
+        # Counter traffic (FETCH_SIZE x2 + WRITE_SIZE per launch) from the committed PMC passes of tools/profile_round.sh.  The file
+        # is stamped with the library's source hash and the configuration: it is used only for THE SAME build and configuration
+        # (a stale file gives null, never a silently wrong number).
+        traffic, traffic_attn, traffic_note, tj = None, None, None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
-            if tj["_config"] == {"model": a.model, "batch": B, "grid": a.grid}:
+            here = open(_hip.LIB_PATH + ".srchash").read().strip() if os.path.exists(_hip.LIB_PATH + ".srchash") else None
+            if tj["_config"] != {"model": a.model, "batch": B, "grid": a.grid}:
+                traffic_note = "profiles/%s is for another configuration" % TRAFFIC_JSON
+            elif tj.get("_srchash") != here:
+                traffic_note = "profiles/%s was collected on another build of the library (srchash differs)" % TRAFFIC_JSON
+            else:
                 traffic = tj["gemm"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        split = None       # Infinity-Cache hits vs HBM reads inside that counter traffic (tools/mall_probe.py: mean L2-miss latency)
+                traffic_attn = {k: tj[k]["hbm_bytes_per_launch"] for k in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv") if k in tj}
+        except Exception as e:
+            traffic_note = "no usable profiles/%s (%s)" % (TRAFFIC_JSON, type(e).__name__)
+        split = None       # Infinity-Cache hits vs HBM reads inside that counter traffic (mean L2-miss latency, tools/mall_probe.py)
         try:
             mj = json.load(open(os.path.join(ROOT, "profiles", MALL_JSON)))
             share = {k: v["infinity_cache_hit_share_est"] for k, v in mj.items() if isinstance(v, dict) and "gemm" in k
                      and "infinity_cache_hit_share_est" in v}
             if share and traffic is not None:
                 lo = min(share.values())
-                alg = gm.get("bytes", None) or 0.0     # compulsory bytes: every operand read once, the result written once
                 split = {"infinity_cache_hit_share_of_reads": share,
-                         "hbm_bytes_per_launch_estimate": max(alg, traffic * (1.0 - lo)),
-                         "method": "mean L2-miss latency (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ) interpolated between an HBM-stream and "
-                                   "an Infinity-Cache-stream calibration, profiles/" + MALL_JSON + "; the estimate is floored at the "
-                                   "algorithmic bytes (a share that clips to 1.0 means the re-reads never leave the die)"}
+                         "hbm_bytes_per_launch_estimate": traffic * (1.0 - lo),       # NOT floored: may read below the algorithmic bytes
+                         "calibration": mj.get("_calibration"),
+                         "method": "mean L2-miss latency (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ) of the kernels INSIDE the bench step, "
+                                   "interpolated between calibration streams (L2-resident, Infinity-Cache-resident, HBM), profiles/"
+                                   + MALL_JSON}
         except Exception:
             split = None
         ach = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["launches"] else 0.0
@@ -484,8 +519,18 @@ def main():
                          "kernel": "orbit2_gemm_bf16 / orbit2_gemm_bf16_grouped (csrc/gemm.hip, hand-written MFMA kernels): "
                                    "EVERY GEMM of the step -- forward, input gradients, weight gradients -- all launches "
                                    "of the timed region; no vendor-library GEMM is called",
+                         "traffic_note": traffic_note,
                          "launches": gm["launches"],
                          "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
+            # the family FURTHEST below its roofline, with the same fields: forward and backward launches of the
+            # flash-attention kernels (csrc/attn.hip); algorithmic FLOPs 4 B H L^2 d forward, 8 B H L^2 d backward (the backward's
+            # recomputation of S and its two-kernel split are NOT credited)
+            "roofline_attention": _attn_roofline(prof, traffic_attn, traffic_note),
+            # the whole step against the same peak: FLOPs the kernels execute (folded variable aggregation) / wall time
+            "roofline_step": {"bound": "mfma", "achieved": 3 * f_exec * sps / world / 1e12, "peak": PEAK_BF16 / 1e12,
+                              "unit": "TFLOP/s", "frac": 3 * f_exec * sps / world / PEAK_BF16,
+                              "note": "executed-FLOP fraction of the step (fwd + loss + bwd + all-reduce + AdamW inside the timed "
+                                      "region); dense-formulation figure in step_model"},
             "step_model": {
                 "model_flops_per_sample_dense": 3 * f_dense, "executed_flops_per_sample_folded_varagg": 3 * f_exec,
                 "mfma_frac_of_peak_dense_formulation": 3 * f_dense * sps / world / PEAK_BF16,
@@ -498,6 +543,15 @@ def main():
                 "attn_ms_per_step": (prof.get("attn_fwd", {"ms": 0})["ms"] + prof.get("attn_bwd", {"ms": 0})["ms"]) / a.steps,
                 "final_loss": loss_val, "loss_scale": scaler.get_scale()},
         }
+        if eng.comm_stats is not None:                   # did the collectives hide behind backward?
+            cst = eng.comm_stats.summary(a.steps)
+            out["comm"] = dict(cst, note="HIP events: comm_ms = busy time of the communication stream in the bucket collectives "
+                                         "(+ unit all-gathers with --fsdp), exposed_comm_ms = what the compute stream waited for "
+                                         "them at the join / at a gathered unit's hand-over; bytes = buffers handed to the collectives",
+                               overlap_fraction=(1.0 - cst["exposed_comm_ms_per_step"] / cst["comm_ms_per_step"])
+                               if cst["comm_ms_per_step"] > 0 else None)
+            out["comm_ms_per_step"] = cst["comm_ms_per_step"]
+            out["exposed_comm_ms"] = cst["exposed_comm_ms_per_step"]
         if world == 1 and (a.eager_baseline or not a.no_cpu_baseline):
             del eng, opt, model, batch
             torch.cuda.empty_cache()

@@ -212,10 +212,10 @@ def main():
         tokens = batch_size * (in_shape[2] // mc["patch_size"]) * (in_shape[3] // mc["patch_size"])
         capturable = world_size == 1 or dist.get_backend() == "nccl"      # gloo rehearsals stage through the host: no capture
         capturable = capturable and getattr(train_loss, "graph_capturable", True)
-        capturable = capturable and not getattr(eng, "shard_params", False)    # gathers / releases are host-driven
-        if hg is True and (tp > 1 or getattr(eng, "shard_params", False) or not capturable):
-            raise ValueError("trainer.hipgraph: true is not available here (tensor parallelism, the parameter-sharding engine, a "
-                             "gloo rehearsal or a loss that reads the host): use 'auto' or false")     # never a silent fallback
+        capturable = capturable and not getattr(eng, "shard_params", False)    # gathers / releases: hipStreamEndCapture crashes on them
+        if hg is True and (tp > 1 or not capturable):
+            raise ValueError("trainer.hipgraph: true is not available here (tensor parallelism, the parameter-sharding engine or a "
+                             "gloo rehearsal): use 'auto' or false")     # never a silent fallback
         use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable)) and tp == 1
         gstep, gshape = None, None
         for epoch in range(epoch_start, max_epochs):

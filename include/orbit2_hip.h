@@ -235,6 +235,9 @@ int orbit2_seed_salt(uint64_t value, int add, void* stream);
 /* hardware self-test of the MFMA / LDS-transpose / LDS-DMA layouts the kernels assume; returns a
  * bitmask of failed checks in result[0] (0 = all good). */
 int orbit2_selftest(int* result, void* stream);
+/* diagnostic: sweep `bytes` of buf with 16-byte loads from `blocks` workgroups, `inflight` (1, 4 or 8) loads per lane at a time --
+ * the calibration streams of the memory-side latency probe (tools/mall_probe.py, bench.py --mall-probe); sink: one float */
+int orbit2_probe_read(const void* buf, int64_t bytes, int blocks, int inflight, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

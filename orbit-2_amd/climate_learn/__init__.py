@@ -12,7 +12,7 @@ _FACTORIES = ("load_model_module load_forecasting_module load_climatebench_modul
               "load_architecture load_optimizer load_lr_scheduler load_loss load_transform").split()
 globals().update({_n: getattr(_loaders, _n) for _n in _FACTORIES})
 from . import data
-from .dist.dp_engine import HipDataParallel
+from .dist.dp_engine import CommStats, HipDataParallel
 from .dist.fsdp_engine import HipFullyShardedDataParallel
 from .optim import HipAdamW, HipGradScaler
 from ._ops import manual_seed

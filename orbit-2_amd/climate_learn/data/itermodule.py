@@ -161,8 +161,26 @@ class IterDataModule(SyntheticGridDataModule):
         if shuffle and self.buffer_size > 0:
             ds = ID.ShuffleIterableDataset(ds, self.buffer_size, seed=self.seed, dp_rank=rd.dp_rank)
             ds.epoch = rd.epoch
-        return DataLoader(ds, batch_size=self.batch_size, drop_last=False, num_workers=self.num_workers,
-                          collate_fn=ID.collate_fn)
+        chain = [rd] + ([ds] if isinstance(ds, ID.ShuffleIterableDataset) else [])
+
+        class _EpochLoader(DataLoader):
+            """DataLoader that numbers its own passes: with num_workers > 0 the workers iterate COPIES of the datasets, so an
+            epoch counter advanced inside their __iter__ never reaches the parent and a re-iterated loader would replay the
+            identical order (round-2 advisor).  The parent sets the epoch of the reader and of the shuffle buffer before every
+            pass -- the workers of that pass are started afterwards and inherit it; `set_epoch(e)` pins it (resume)."""
+
+            def set_epoch(self, epoch: int):
+                self._o2_epoch = int(epoch)
+
+            def __iter__(self):
+                e = getattr(self, "_o2_epoch", chain[0].epoch)
+                for d in chain:
+                    d.epoch = e
+                self._o2_epoch = e + 1
+                return super().__iter__()
+
+        return _EpochLoader(ds, batch_size=self.batch_size, drop_last=False, num_workers=self.num_workers,
+                            collate_fn=ID.collate_fn)
 
     def train_dataloader(self):
         return self._loader("train", True) if self.on_disk else super().train_dataloader()

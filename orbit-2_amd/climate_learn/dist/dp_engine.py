@@ -67,6 +67,31 @@ class Bucket:
         self.rep_views: List[torch.Tensor] = []    # gradient ranges of the parameters replicated over a tensor-parallel group
 
 
+class CommStats:
+    """Per-step communication accounting of an engine (bench.py --gpus N, tests): HIP-event spans on the communication
+    stream around every bucket collective (`comm_ms`: how long the stream was busy with them), the compute stream's stall at
+    the join in finish_grad_sync / at a gathered unit's hand-over (`exposed_ms`: communication that did NOT hide behind
+    compute) and the bytes handed to the collectives.  Off unless `engine.comm_stats` is set: the collectives are then
+    waited for on the communication stream right after their launch (stream-ordered for RCCL: nothing blocks the host or the
+    compute stream), so that an end event can be recorded behind them."""
+
+    def __init__(self):
+        self.spans, self.stalls = [], []
+        self.bytes = 0
+        self.launches = 0
+
+    @staticmethod
+    def _ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def summary(self, steps: int = 1):
+        torch.cuda.synchronize()
+        comm = sum(a.elapsed_time(b) for a, b in self.spans)
+        exposed = sum(a.elapsed_time(b) for a, b in self.stalls)
+        return {"comm_ms_per_step": comm / steps, "exposed_comm_ms_per_step": exposed / steps,
+                "comm_bytes_per_step": self.bytes / steps, "collectives_per_step": self.launches / steps}
+
+
 class HipDataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (),
                  is_lowp=None, sync_module_states: bool = True, overlap: bool = True,
@@ -208,6 +233,7 @@ class HipDataParallel(nn.Module):
                            group=self.pg)
             self.refresh_compute_copies()
         self.comm_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
+        self.comm_stats: Optional[CommStats] = None      # set to a CommStats() to account communication (bench, tests)
         self._launched: List[Bucket] = []
         self.zero_grad()
 
@@ -260,14 +286,26 @@ class HipDataParallel(nn.Module):
         self._launched.append(bk)
         if self.world == 1 and not self.force_comm:
             return
+        cs = self.comm_stats
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if cs is not None:
+                    e0, e1 = cs._ev(), cs._ev()
+                    e0.record(self.comm_stream)
                 bk.handle = [self._reduce(bk, v) for v in bk.grad_views]
+                if cs is not None:
+                    for h in bk.handle:
+                        h.wait()                      # stream-ordered: the communication stream (only) waits for the collective
+                    e1.record(self.comm_stream)
+                    cs.spans.append((e0, e1))
         else:
             bk.handle = [self._reduce(bk, v) for v in bk.grad_views]
+        if cs is not None:
+            cs.bytes += sum(v.numel() * v.element_size() for v in bk.grad_views)
+            cs.launches += len(bk.grad_views)
 
     def _gather_ranges(self, flat: torch.Tensor, which: int):
         """all-gather every unit's low-precision range of `flat` (flat16: which = 1, flat32: which = 0) from the
@@ -313,7 +351,15 @@ class HipDataParallel(nn.Module):
                     h.wait()
                 bk.handle = None           # idempotent: a second call (e.g. scaler.step after a captured step) is a no-op
         if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cs = self.comm_stats
+            if cs is not None and self._launched and (self.world > 1 or self.force_comm):
+                e0, e1 = cs._ev(), cs._ev()
+                e0.record(torch.cuda.current_stream())          # the last backward kernel has been queued
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                e1.record(torch.cuda.current_stream())          # ... e1 - e0 = what the compute stream waited for communication
+                cs.stalls.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         if self.replica_group is not None and not self._replicas_synced:
             for bk in self.buckets:
                 for v in bk.rep_views:

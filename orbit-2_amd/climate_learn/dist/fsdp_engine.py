@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .dp_engine import BF, F32, Bucket, _ALIGN, _round_up, default_units
+from .dp_engine import BF, F32, Bucket, CommStats, _ALIGN, _round_up, default_units
 
 
 class _Unit(Bucket):
@@ -251,6 +251,7 @@ class HipFullyShardedDataParallel(nn.Module):
         self._pfree_ev = [None] * pool_size            # compute-stream events: last kernel using the buffer has been queued
         self._gfree_ev = [None, None]                  # communication-stream events: reduce-scatter of the buffer done
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.comm_stats: Optional[CommStats] = None      # set to a CommStats() to account communication (bench, tests)
         self._order: List[_Unit] = []                  # execution order of the sharded units in forward (recorded)
         self._recording = True
         self._launched: List[_Unit] = []
@@ -308,8 +309,17 @@ class HipFullyShardedDataParallel(nn.Module):
             if ev is not None:
                 self.comm_stream.wait_event(ev)            # the buffer's previous user has finished computing
             self.comm_stream.wait_stream(torch.cuda.current_stream())     # chunk16 is current (AdamW / cast ran on the compute stream)
+            cs = self.comm_stats
             with torch.cuda.stream(self.comm_stream):
+                if cs is not None:
+                    e0, e1 = cs._ev(), cs._ev()
+                    e0.record(self.comm_stream)
                 run()
+                if cs is not None:
+                    e1.record(self.comm_stream)
+                    cs.spans.append((e0, e1))
+                    cs.bytes += buf.numel() * buf.element_size()
+                    cs.launches += 1
                 u.pevent = torch.cuda.Event()
                 u.pevent.record(self.comm_stream)
         else:
@@ -318,7 +328,15 @@ class HipFullyShardedDataParallel(nn.Module):
     def _acquire(self, u: _Unit):
         self._issue_gather(u)
         if u.pevent is not None:
-            torch.cuda.current_stream().wait_event(u.pevent)
+            cs = self.comm_stats
+            if cs is not None:                       # how long the compute stream waits for the gathered unit
+                e0, e1 = cs._ev(), cs._ev()
+                e0.record(torch.cuda.current_stream())
+                torch.cuda.current_stream().wait_event(u.pevent)
+                e1.record(torch.cuda.current_stream())
+                cs.stalls.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_event(u.pevent)
             u.pevent = None
         buf = self.ppool[u.pbuf]
         for p, off, k in u.members:
@@ -444,11 +462,21 @@ class HipFullyShardedDataParallel(nn.Module):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            cs = self.comm_stats
             with torch.cuda.stream(self.comm_stream):
+                if cs is not None:
+                    e0, e1 = cs._ev(), cs._ev()
+                    e0.record(self.comm_stream)
                 u.handle = self._reduce_views(u)
-                if u.sharded:
+                if u.sharded or cs is not None:
                     for h in u.handle:
                         h.wait()                      # stream-ordered for NCCL work: later communication-stream work follows it
+                if cs is not None:
+                    e1.record(self.comm_stream)
+                    cs.spans.append((e0, e1))
+                    cs.bytes += (u.n * 2 if u.sharded else sum(v.numel() * v.element_size() for v in u.grad_views))
+                    cs.launches += 1
+                if u.sharded:
                     gev = torch.cuda.Event()
                     gev.record(self.comm_stream)
                     self._gfree_ev[u.gbuf] = gev
@@ -478,7 +506,15 @@ class HipFullyShardedDataParallel(nn.Module):
         for u in self.sharded_units:                    # a unit whose input needed no gradient never saw post_backward
             self._release(u)
         if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cs = self.comm_stats
+            if cs is not None and self._launched:
+                e0, e1 = cs._ev(), cs._ev()
+                e0.record(torch.cuda.current_stream())
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                e1.record(torch.cuda.current_stream())
+                cs.stalls.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         if self.tp_group is not None and not self._replicas_synced:
             from . import tp as _tp
             for u in self.units:

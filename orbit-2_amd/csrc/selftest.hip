@@ -114,3 +114,36 @@ extern "C" int orbit2_selftest(int* result, void* stream) {
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
+
+// ---- memory-side latency calibration (diagnostic: tools/mall_probe.py, bench.py --mall-probe) ---------------------------------
+// `blocks` workgroups of 256 threads sweep `bytes` of `buf` with 16-byte loads, `inflight` (1..8) independent loads per lane at
+// a time.  Run under rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum, a sweep of a buffer that fits the 256 MB
+// Infinity Cache (but not the 32 MB of L2) gives the mean L2-miss latency of an Infinity-Cache HIT, a sweep of a multi-GB buffer
+// that of an HBM read -- each at a chosen load (few blocks with one load in flight: near the unloaded latency; a full grid with
+// eight: the latency under a saturating stream).  The product kernels' own mean latencies are read against these brackets.
+namespace {
+template <int INF>
+__global__ __launch_bounds__(256) void probe_read_kernel(const u32x4* __restrict__ buf, int64_t n16, float* __restrict__ sink) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * INF;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * INF; i + INF <= n16; i += stride) {
+    u32x4 v[INF];
+#pragma unroll
+    for (int j = 0; j < INF; ++j) v[j] = __builtin_nontemporal_load(buf + i + j);
+#pragma unroll
+    for (int j = 0; j < INF; ++j) acc ^= v[j];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) sink[0] = 1.f;     // keeps the loads alive; practically never taken
+}
+}  // namespace
+
+extern "C" int orbit2_probe_read(const void* buf, int64_t bytes, int blocks, int inflight, float* sink, void* stream) {
+  if (!buf || !sink || bytes < 16 || blocks <= 0) return O2_ERR_ARG;
+  const int64_t n16 = bytes / 16;
+  hipStream_t s = (hipStream_t)stream;
+  if (inflight >= 8) hipLaunchKernelGGL(probe_read_kernel<8>, dim3(blocks), dim3(256), 0, s, (const u32x4*)buf, n16, sink);
+  else if (inflight >= 4) hipLaunchKernelGGL(probe_read_kernel<4>, dim3(blocks), dim3(256), 0, s, (const u32x4*)buf, n16, sink);
+  else hipLaunchKernelGGL(probe_read_kernel<1>, dim3(blocks), dim3(256), 0, s, (const u32x4*)buf, n16, sink);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

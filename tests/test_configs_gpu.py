@@ -199,20 +199,22 @@ def test_interm_1b_daymet_like_hybrid_perceptual_step(monkeypatch):
             assert torch.isfinite(v.float()).all() and float(v.float().abs().sum()) > 0, bk.name
     g1 = model.blocks[7].attn.qkv.weight._o2g.clone()
     gh = model.head[8].weight._o2g.clone()
-    l2 = one(mark)                                           # same seeds: bit-identical
-    assert float(l2) == float(l1) and torch.equal(model.blocks[7].attn.qkv.weight._o2g, g1) and torch.equal(model.head[8].weight._o2g, gh)
-    l3 = one()                                               # fresh dropout / DropPath masks
-    assert float(l3) != float(l1) and not torch.equal(model.blocks[7].attn.qkv.weight._o2g, g1)
+    l2 = one(mark)           # same seeds: the same masks -> the same step up to the summation order of the loss's float atomics
+    assert abs(float(l2) - float(l1)) < 1e-5 * abs(float(l1))
+    assert rel_l2(model.blocks[7].attn.qkv.weight._o2g, g1) < 2e-3 and rel_l2(model.head[8].weight._o2g, gh) < 2e-3
+    l3 = one()                                               # fresh dropout / DropPath masks: a different step
+    assert abs(float(l3) - float(l1)) > 1e-5 * abs(float(l1)) and rel_l2(model.blocks[7].attn.qkv.weight._o2g, g1) > 5e-2
     scaler.step(opt)
     assert scaler.update() is False
     # the loss object on the step's own predictions against the oracle (CPU, fp32): L1 + 0.5 LPIPS + lat-weighted MSE
     eng.eval()
     with torch.no_grad():
         pred = eng(batch[0], in_vars, OUT_VARS)
+        raw = pred.clone()                                      # clip_replace_constant clamps precipitation IN PLACE
         yhat = clip_replace_constant(batch[1], pred, OUT_VARS)
         val = loss_fn(yhat, batch[1], var_names=OUT_VARS, var_weights=VW)
         p1 = eng(batch[0][1:2].contiguous(), in_vars, OUT_VARS)
-    assert pred.shape == (B, 3, 4 * h, 4 * w) and torch.equal(pred[1:2], p1)         # batch independence
+    assert raw.shape == (B, 3, 4 * h, 4 * w) and torch.equal(raw[1:2], p1)          # batch independence
     yc, tc = yhat.float().cpu(), batch[1].float().cpu()
     lp = float(O.lpips_vgg(yc, tc, sd_l).mean())
     ref = float((yc - tc).abs().mean()) + 0.5 * lp + float(O.mse(yc, tc, OUT_VARS, VW, True, O.lat_weights(lat, 4 * h)))

@@ -108,6 +108,17 @@ def test_iterdatamodule_on_disk(tmp_path):
     x, y, a, b = batches[0]
     assert x.shape[1:] == (5, h, w) and y.shape[1:] == (1, H, W) and a == iv and b == ov
     assert float(y.min()) >= 0.0                                    # log1p precipitation
+    # a loader that is RE-ITERATED draws a new order every pass, also with worker processes (they iterate copies of the
+    # datasets: the loader itself numbers its passes, round-2 advisor), and set_epoch() reproduces a pass
+    dmw = cl.data.IterDataModule("downscaling", str(lo_root), str(hi_root), iv, ov, batch_size=4, buffer_size=8,
+                                 div=2, overlap=2, subsample=1, num_workers=1)
+    dmw.setup()
+    ld = dmw.train_dataloader()
+    key = lambda bs: [float(v) for b_ in bs for v in b_[1].reshape(b_[1].shape[0], -1).sum(1)]
+    p0, p1 = key(list(ld)), key(list(ld))
+    assert sorted(p0) == sorted(p1) and p0 != p1                     # the same samples, another order
+    ld.set_epoch(0)
+    assert key(list(ld)) == p0
 
 
 def _shard_worker(rank, world, root, port, q):

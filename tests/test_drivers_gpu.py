@@ -312,6 +312,16 @@ def test_bench_contract_two_ranks_one_card(tmp_path):
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job samples / max-rank time
     assert d["roofline"]["launches"] > 0
+    # communication accounting of the timed region: did the bucket collectives hide behind backward?
+    c = d["comm"]
+    assert d["comm_ms_per_step"] == c["comm_ms_per_step"] > 0 and d["exposed_comm_ms"] == c["exposed_comm_ms_per_step"] >= 0
+    assert c["collectives_per_step"] >= 5                       # one or two ranges per unit: 2 Blocks... + path2 + head + root
+    nparam = d["config"]["params"]
+    assert 2 * nparam <= c["comm_bytes_per_step"] <= 4.5 * nparam      # bf16 buckets + the fp32 ranges of the fp32-compute parameters
+    assert d["roofline_attention"]["launches"] > 0 and 0 < d["roofline_attention"]["frac"] < 1
+    assert 0 < d["roofline_step"]["frac"] < 1
+    f = run(["--fsdp"])                                          # parameter sharding: + the units' all-gathers (forward and backward)
+    assert f["comm"]["collectives_per_step"] > c["collectives_per_step"] and f["comm"]["comm_bytes_per_step"] > c["comm_bytes_per_step"]
     t = run(["--tensor-par", "2"])
     assert t["config"]["parallelism"] == "dp1xtp2" and t["config"]["global_batch"] == 2
     assert abs(t["value"] - 2 * 1e3 / t["ms_per_step"]) < 1e-6 * t["value"]

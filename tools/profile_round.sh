@@ -1,7 +1,7 @@
 set -e
 # usage (on the GPU box): bash tools/profile_round.sh [tag]  -- rocprofv3 passes of the default bench configuration
 # (kernel stats; FETCH_SIZE; WRITE_SIZE; MFMA-busy + clock; optional DRAM/MALL counters when the box lists them)
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof
@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof -o ${TAG}_w
 echo write-done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof -o ${TAG}_mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_mfma.log 2>&1
 echo mfma-done
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d $R/gpurun_out/prof -o ${TAG}_mall -- python3 $R/tools/mall_probe.py > $R/gpurun_out/prof_mall.log 2>&1 || echo "mall pass failed (see prof_mall.log)"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum --output-format csv -d $R/gpurun_out/prof -o ${TAG}_mall -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mall-probe > $R/gpurun_out/prof_mall.log 2>&1 || echo "mall pass failed (see prof_mall.log)"
 echo mall-done
 cd $R
 python tools/summarize_prof.py mall gpurun_out/prof/${TAG}_mall_counter_collection.csv gpurun_out/${TAG}_mall_latency.json > gpurun_out/${TAG}_mall_latency.txt 2>&1 || true

@@ -70,46 +70,66 @@ def traffic(fetch_csv, write_csv, out):
                     "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B), counter unit KB; FETCH_SIZE "
                     "is L2-miss traffic (Infinity-Cache hits included)")
     res["_config"] = {"model": "interm_1b", "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 8, "grid": "128x256"}
+    # the build the counters belong to: bench.py uses this file only for a library with the same source hash
+    import os
+    sh = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "orbit-2_amd", "lib", "liborbit2_hip.so.srchash")
+    res["_srchash"] = open(sh).read().strip() if os.path.exists(sh) else None
     json.dump(res, open(out, "w"), indent=1)
 
 
 def mall(path, out):
-    """TCC_EA0_RDREQ / _LEVEL / _DRAM pass of tools/mall_probe.py -> mean L2-miss latency per kernel and the Infinity-Cache
-    hit share interpolated between the two calibration streams (hbm = bf16 reduce of 4 GB, mall = fp32 reduce of 96 MB)."""
+    """TCC_EA0_RDREQ / _LEVEL pass of `bench.py --mall-probe` (or tools/mall_probe.py) -> mean L2-miss latency per kernel of the
+    step and the Infinity-Cache hit share, read against FOUR calibration streams run in the same process
+    (_hip.mall_calibration: orbit2_probe_read on a 96 MB buffer = Infinity-Cache hits, and on a 4 GB buffer = HBM reads, each
+    lightly loaded -- 64 workgroups, one load in flight -- and under a saturating stream -- 2048 workgroups, eight in flight)."""
     import json
     rows = list(csv.DictReader(open(path)))
-    agg = collections.OrderedDict()
+    per = collections.OrderedDict()                      # dispatch -> counters (dispatch order = launch order)
     for r in rows:
-        n = r["Kernel_Name"]
-        if "reduce_kernel" in n:
-            k = "calibration_hbm_stream(4GB bf16 sum)" if "BFloat16" in n else "calibration_mall_stream(96MB fp32 sum)"
+        d = per.setdefault(int(r["Dispatch_Id"]), {"k": r["Kernel_Name"]})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    agg = collections.OrderedDict()
+    seen = {"<1>": 0, "<8>": 0}
+    for did in sorted(per):
+        d = per[did]
+        n = d["k"]
+        if "probe_read_kernel" in n:
+            tag = "<1>" if "<1>" in n else "<8>"
+            i = seen[tag]
+            seen[tag] += 1
+            if tag == "<8>":
+                k = None if i == 0 else ("calibration_infinity_cache_saturating" if i <= 6 else "calibration_hbm_saturating")
+            else:
+                k = "calibration_infinity_cache_light" if i < 6 else "calibration_hbm_light"
+            if k is None:
+                continue                                 # the sweep that fills the Infinity Cache
         else:
             k = short(n)
-            if not any(s in k for s in ("gemm", "attn_fwd", "attn_bwd")):
+            if not any(s_ in k for s_ in ("gemm", "attn_fwd", "attn_bwd")):
                 continue
-        agg.setdefault(k, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        a_ = agg.setdefault(k, collections.defaultdict(float))
+        a_["req"] += d.get("TCC_EA0_RDREQ_sum", 0.0)
+        a_["lvl"] += d.get("TCC_EA0_RDREQ_LEVEL_sum", 0.0)
+        a_["n"] += 1
     res = collections.OrderedDict()
-    for k, d in agg.items():
-        req, lvl = d.get("TCC_EA0_RDREQ_sum", []), d.get("TCC_EA0_RDREQ_LEVEL_sum", [])
-        if k.startswith("calibration_mall") and len(req) > 4:      # the first pass is the cold one
-            req, lvl = req[2:], lvl[2:]
-        dram = d.get("TCC_EA0_RDREQ_DRAM_sum", [])
-        if not req or sum(req) == 0:
-            continue
-        res[k] = {"dispatches": len(req), "rdreq_per_dispatch": sum(req) / len(req),
-                  "mean_l2_miss_latency_cycles": sum(lvl) / sum(req),
-                  "rdreq_dram_share": (sum(dram) / sum(d.get("TCC_EA0_RDREQ_sum", [1]))) if dram else None}
-    ch = [v for k, v in res.items() if k.startswith("calibration_hbm")]
-    cm = [v for k, v in res.items() if k.startswith("calibration_mall")]
-    if ch and cm:
-        lh, lm = ch[0]["mean_l2_miss_latency_cycles"], cm[0]["mean_l2_miss_latency_cycles"]
+    for k, a_ in agg.items():
+        if a_["req"] > 0:
+            res[k] = {"dispatches": int(a_["n"]), "rdreq_per_dispatch": a_["req"] / a_["n"],
+                      "mean_l2_miss_latency_cycles": a_["lvl"] / a_["req"]}
+    cal = {k[len("calibration_"):]: v["mean_l2_miss_latency_cycles"] for k, v in res.items() if k.startswith("calibration_")}
+    if {"infinity_cache_saturating", "hbm_saturating"} <= set(cal):
+        lm, lh = cal["infinity_cache_saturating"], cal["hbm_saturating"]
         for k, v in res.items():
             if not k.startswith("calibration"):
-                f = (lh - v["mean_l2_miss_latency_cycles"]) / (lh - lm) if lh != lm else float("nan")
-                v["infinity_cache_hit_share_est"] = max(0.0, min(1.0, f))
+                lat = v["mean_l2_miss_latency_cycles"]
+                v["infinity_cache_hit_share_est"] = max(0.0, min(1.0, (lh - lat) / (lh - lm))) if lh != lm else float("nan")
+                lo = cal.get("infinity_cache_light")
+                # a latency inside [lightly loaded hit, saturated hit] is an Infinity-Cache-served stream at an intermediate load
+                v["within_infinity_cache_bracket"] = bool(lo is not None and lo <= lat <= lm)
+    res["_calibration"] = cal
     res["_note"] = ("TCC_EA0_RDREQ_LEVEL_sum / TCC_EA0_RDREQ_sum = mean latency of an L2 miss (TCC cycles); hit share = linear "
-                    "interpolation between the HBM-stream and the Infinity-Cache-stream calibrations run in the same process; "
-                    "TCC_EA0_RDREQ_DRAM counts requests routed to local memory (vs GMI / IO), not Infinity-Cache misses")
+                    "interpolation between the saturating HBM and Infinity-Cache streams; `within_infinity_cache_bracket`: the "
+                    "latency lies between the lightly loaded and the saturated Infinity-Cache calibration")
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
         print(k, v)
