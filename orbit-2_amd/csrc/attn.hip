@@ -1091,6 +1091,246 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
     }
 }
 
+// =============================================================================================
+// backward, dK and dV of d = 256 (interm_10b) in ONE pass: the construction of attn_bwd_dkv128_kernel at one wave per SIMD.
+// 128 keys per workgroup (4 waves x 32), 512 registers per wave: dK (128) + dV (128) accumulators, K fragments (64), the
+// wave's V rows in LDS (64 KB for the workgroup) feeding the dP MFMAs by ds_read_b128.  The LDS holds that plus two stages of
+// 32-ROW Q / dO tiles (2 x 2 x 16 KB): a tile = one query block = 64 MFMAs per wave (S 16, dP 16, dV 16, dK 16) against the
+// two-pass form's 48 + 32 + a second softmax / dropout recomputation.  Same per-element arithmetic and accumulation order as the
+// split passes: bit-identical dK / dV (tests/test_hip_ops.py::test_attention_dkv_one_pass_equals_two_passes).
+//   * row fragments of a 512-byte row: chunk c = 2 ds + h, the swizzle touches its low 4 bits only, so k-steps ds and ds + 8 are
+//     one address register + 256 (8 registers serve 16 k-steps); transposed blocks db and db + 4 likewise (8 registers serve 8);
+//   * the tile loop is unrolled by two (compile-time stage index: every LDS address is a register + immediate);
+//   * one k-step of operands in flight, pinned by sched_barrier (as in the d = 128 kernel).
+// =============================================================================================
+template <bool DROP, bool RAGGED>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* __restrict__ qkv,
+                                                                 const bf16_t* __restrict__ dout,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 bf16_t* __restrict__ dqkv, int L, int H, float scale,
+                                                                 unsigned thr, float dscale, uint64_t seed_arg, float opmul,
+                                                                 float kgrad) {
+  constexpr int D = 256, NW = 4, TR = 32;                    // TR: query rows per staged tile
+  using C = Cfg<D>;
+  constexpr int TILE = TR * C::RB;                           // 16 KB
+  constexpr int VOFF = 4 * TILE, SOFF = VOFF + NW * 32 * C::RB;      // [2][Q|dO] | V rows of the workgroup | [2][lse2|delta|row hash]
+  __shared__ __attribute__((aligned(16))) char smem[SOFF + 2 * 3 * TR * 4];
+  const uint64_t seed = seed_arg ^ o2_seed_salt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hq = lane >> 5;
+  int tile_i, head, b;
+  attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
+  const int k0 = tile_i * (NW * 32) + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;
+  const size_t ostride = (size_t)H * D;
+  const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
+  const bf16_t* kbase = qbase + (size_t)H * D;
+  const bf16_t* vbase = qbase + (size_t)2 * H * D;
+  const bf16_t* dobase = dout + (size_t)b * L * ostride + (size_t)head * D;
+  const int krow_raw = k0 + (lane & 31);
+  const bool k_ok = !RAGGED || krow_raw < L;
+  const int krow = k_ok ? krow_raw : L - 1;
+  float* sstat = reinterpret_cast<float*>(smem + SOFF);
+
+  // stage ROWS rows (a multiple of 2 * NW) of a [rows][256] bf16 matrix: 1-KiB pieces of two rows each, swizzled source
+  auto stage_rows = [&](const bf16_t* base, size_t stride, char* tile, int rows, int nvalid) {
+    const int pieces = rows / 2 / NW;                        // per wave
+    for (int t = 0; t < pieces; ++t) {
+      const int i = wave * pieces + t;
+      const int row = i * 2 + lane / 32;
+      const int c = (lane % 32) ^ swz<D>(row);
+      const int rsrc = (!RAGGED || row < nvalid) ? row : nvalid - 1;
+      const uint32_t off = ((uint32_t)rsrc * (uint32_t)stride + (uint32_t)(c * 8)) * 2u;
+      glds16(reinterpret_cast<const char*>(base) + off, tile + i * 1024);
+    }
+  };
+
+  bf16x8 kf[C::NDS];
+#pragma unroll
+  for (int ds = 0; ds < C::NDS; ++ds)
+    kf[ds] = scale_frag(*reinterpret_cast<const bf16x8*>(kbase + (size_t)krow * tstride + ds * 16 + 8 * hq), opmul);
+  {
+    int start = tile_i * (NW * 32), nv = L - start;
+    if (RAGGED && nv < 1) { start = L - 1; nv = 1; }
+    stage_rows(vbase + (size_t)start * tstride, tstride, smem + VOFF, NW * 32, nv);
+  }
+  f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+  for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  // ---- LDS addresses (32-bit): row fragments of row lane&31 for k-steps 0..7 (+256: k-steps 8..15), transposed blocks 0..3 (+256: 4..7)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  uint32_t rq[8];
+  {
+    const int r = lane & 31;
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) rq[ds] = lds0 + r * C::RB + (((ds * 2 + hq) ^ swz<D>(r)) << 4);
+  }
+  const uint32_t vwoff = VOFF + wave * 32 * C::RB;           // this wave's 32 V rows
+  uint32_t t0[4], t1[4];
+  {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = 4 * hq + q, row1 = row + 8;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const int c = db * 4 + 2 * (g & 1) + (p >> 1);
+      t0[db] = lds0 + row * C::RB + ((c ^ swz<D>(row)) << 4) + 8 * (p & 1);
+      t1[db] = lds0 + row1 * C::RB + ((c ^ swz<D>(row1)) << 4) + 8 * (p & 1);
+    }
+  }
+  auto ld128 = [](uint32_t a) { return *(const __attribute__((address_space(3))) bf16x8*)(a); };
+  auto ldf4 = [](uint32_t a) { return *(const __attribute__((address_space(3))) f32x4*)(a); };
+  auto ldtr = [](uint32_t a0, uint32_t a1) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  const uint32_t st4 = lds0 + SOFF + 16 * hq;                               // + ((buf*3 + which)*TR + 8*g4) * 4
+  const uint32_t sh1 = lds0 + SOFF + (4 * hq + (lane & 3)) * 4;
+
+  const size_t sbase = ((size_t)(b * H + head)) * L;
+  const uint64_t bh = (uint64_t)(b * H + head);
+  const uint32_t keyhash = DROP ? o2_attn_keyhash(seed, (uint32_t)(krow >> 2)) : 0u;   // this lane's key group
+  const uint32_t kbyte = 8 * (krow & 3);
+  const uint32_t bmask = 0xffu << kbyte, thrs = thr << kbyte;
+  const int nt = (L + TR - 1) / TR;
+  const int nt2 = (nt + 1) & ~1;                            // whole pairs of tiles (a tile past the end contributes nothing)
+  auto stage_stats = [&](int t, int buf) {
+    if (tid < 2 * TR) {
+      const int which = tid / TR, i = tid % TR;
+      float v;
+      if (t * TR + i < L)
+        v = which ? (DROP ? delta[sbase + t * TR + i] / dscale : delta[sbase + t * TR + i])
+                  : lse[sbase + t * TR + i] * 1.4426950408889634f;
+      else
+        v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
+      sstat[(buf * 3 + which) * TR + i] = -v;   // stored NEGATED: the S and dP accumulators start from these rows
+    } else if (DROP && tid < 3 * TR) {   // dropout: hashes of the tile's query rows
+      const int i = tid % TR;
+      reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * TR + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * TR + i));
+    }
+  };
+  auto stage_tile = [&](int t, int buf) {
+    int start = t * TR, nv = L - start;
+    if (nv < 1) { start = 0; nv = L < TR ? L : TR; }       // tile past the end: any valid rows (its statistics zero it)
+    stage_rows(qbase + (size_t)start * tstride, tstride, smem + buf * 2 * TILE, TR, nv);
+    stage_rows(dobase + (size_t)start * ostride, ostride, smem + buf * 2 * TILE + TILE, TR, nv);
+    stage_stats(t, buf);
+  };
+  stage_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto body = [&](auto CURTAG, int t) {
+    constexpr int CUR = decltype(CURTAG)::value;
+    constexpr int QO = CUR * 2 * TILE, DOO = QO + TILE;
+    if (t + 1 < nt2) stage_tile(t + 1, CUR ^ 1);
+    // S[q x key] = Q . K^T - lse2, dP[q x key] = dO . V^T - delta  (rows = queries in registers, column = key on the lane)
+    f32x16 s, dp;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 a4 = ldf4(st4 + ((CUR * 3 + 0) * TR + 8 * g4) * 4);
+      const f32x4 c4 = ldf4(st4 + ((CUR * 3 + 1) * TR + 8 * g4) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a4[e]; dp[4 * g4 + e] = c4[e]; }
+    }
+    uint32_t vw = vwoff;
+    asm volatile("" : "+s"(vw));          // keep the V addresses out of registers: one v_add per read instead
+    auto rowaddr = [&](int ds) { return rq[ds & 7] + (ds >> 3) * 256; };
+    bf16x8 qf = ld128(rowaddr(0) + QO), dof = ld128(rowaddr(0) + DOO), vf = ld128(rowaddr(0) + vw);
+#pragma unroll
+    for (int ds = 0; ds < C::NDS; ++ds) {
+      bf16x8 qn = qf, don = dof, vn = vf;
+      if (ds + 1 < C::NDS) { qn = ld128(rowaddr(ds + 1) + QO); don = ld128(rowaddr(ds + 1) + DOO); vn = ld128(rowaddr(ds + 1) + vw); }
+      s = MFMA32(qf, kf[ds], s);
+      dp = MFMA32(dof, vf, dp);
+      __builtin_amdgcn_sched_barrier(0);
+      qf = qn; dof = don; vf = vn;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t hmine[4] = {0u, 0u, 0u, 0u};
+    if (DROP) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        hmine[g4] = o2_attn_mix(*(const __attribute__((address_space(3))) uint32_t*)(sh1 + ((CUR * 3 + 2) * TR + 8 * g4) * 4), keyhash);
+    }
+    u32x4 pfw[2], dsw[2];     // P after dropout (for dV) and dS (for dK) as the operands of k-steps ss = 0, 1
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 ndl4 = {0.f, 0.f, 0.f, 0.f};
+      if (DROP) ndl4 = ldf4(st4 + ((CUR * 3 + 1) * TR + 8 * g4) * 4);   // -delta
+      float pv[4], dsv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        const float p = __builtin_amdgcn_exp2f(s[r]);
+        float dpr = dp[r];            // dP - delta
+        float pdr = p;
+        if (DROP) {
+          const bool keep = (quad_bcast(hmine[g4], e) & bmask) >= thrs;
+          dpr = keep ? dpr : ndl4[e];     // a dropped element: 0 - delta  (dscale is applied once, on the final dK / dV tiles)
+          pdr = keep ? p : 0.f;
+          asm volatile("" : "+v"(pdr));   // select in fp32, then convert pairs
+        }
+        pv[e] = pdr;
+        dsv[e] = p * dpr;  // dS
+      }
+      pfw[g4 >> 1][2 * (g4 & 1)] = cvt_pk_bf2(pv[0], pv[1]);
+      pfw[g4 >> 1][2 * (g4 & 1) + 1] = cvt_pk_bf2(pv[2], pv[3]);
+      dsw[g4 >> 1][2 * (g4 & 1)] = cvt_pk_bf2(dsv[0], dsv[1]);
+      dsw[g4 >> 1][2 * (g4 & 1) + 1] = cvt_pk_bf2(dsv[2], dsv[3]);
+    }
+    const bf16x8 pf[2] = {__builtin_bit_cast(bf16x8, pfw[0]), __builtin_bit_cast(bf16x8, pfw[1])};
+    const bf16x8 dsf[2] = {__builtin_bit_cast(bf16x8, dsw[0]), __builtin_bit_cast(bf16x8, dsw[1])};
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      auto trd = [&](int j, int off) {     // j = ss * NDB + db
+        const int db = j % C::NDB, ss = j / C::NDB;
+        const uint32_t ro = (ss * 16) * C::RB + off + (db >> 2) * 256;
+        return ldtr(t0[db & 3] + ro, t1[db & 3] + ro);
+      };
+      bf16x8 fd = trd(0, DOO), fq = trd(0, QO);
+#pragma unroll
+      for (int j = 0; j < 2 * C::NDB; ++j) {
+        bf16x8 fdn = fd, fqn = fq;
+        if (j + 1 < 2 * C::NDB) { fdn = trd(j + 1, DOO); fqn = trd(j + 1, QO); }
+        dv[j % C::NDB] = MFMA32(fd, pf[j / C::NDB], dv[j % C::NDB]);     // dV^T += dO^T . P
+        dk[j % C::NDB] = MFMA32(fq, dsf[j / C::NDB], dk[j % C::NDB]);    // dK^T += Q^T . dS
+        __builtin_amdgcn_sched_barrier(0);
+        fd = fdn; fq = fqn;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int t = 0; t < nt2; t += 2) {
+    body(IC<0>{}, t);
+    body(IC<1>{}, t + 1);
+  }
+  if (!k_ok) return;
+  bf16_t* dkrow = dqkv + ((size_t)b * L + krow) * tstride + (size_t)H * D + (size_t)head * D;
+  bf16_t* dvrow = dkrow + (size_t)H * D;
+  const float fk = DROP ? kgrad * dscale : kgrad, fv = DROP ? dscale : 1.0f;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dd = db * 32 + 8 * g4 + 4 * hq;
+      u32x2 w;
+      w[0] = pack_bf2(dk[db][4 * g4] * fk, dk[db][4 * g4 + 1] * fk);
+      w[1] = pack_bf2(dk[db][4 * g4 + 2] * fk, dk[db][4 * g4 + 3] * fk);
+      *reinterpret_cast<u32x2*>(dkrow + dd) = w;
+      w[0] = pack_bf2(dv[db][4 * g4] * fv, dv[db][4 * g4 + 1] * fv);
+      w[1] = pack_bf2(dv[db][4 * g4 + 2] * fv, dv[db][4 * g4 + 3] * fv);
+      *reinterpret_cast<u32x2*>(dvrow + dd) = w;
+    }
+}
+
 }  // namespace
 
 O2_DEFINE_SALT_OP(attn)
@@ -1177,6 +1417,9 @@ static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, co
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
                        dscale, seed, opmul, kgrad);
+  } else if (DV == 256 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {             // one pass at one wave per SIMD (interm_10b)
+    hipLaunchKernelGGL((attn_bwd_dkv256_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
+                       seed, opmul, kgrad);
   } else if (DV == 128 && NW == 8 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {   // one pass, V rows in LDS
     hipLaunchKernelGGL((attn_bwd_dkv128_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
                        seed, opmul, kgrad);

@@ -274,13 +274,15 @@ def test_attention_fwd_bwd(hip, d, H, L, B, p):
         assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
 
 
-@pytest.mark.parametrize("L", [256, 257, 300, 320, 511, 513, 1024 + 96, 2048])
+@pytest.mark.parametrize("d,L", [(128, 256), (128, 257), (128, 300), (128, 320), (128, 511), (128, 513), (128, 1024 + 96), (128, 2048),
+                                 (256, 20), (256, 128), (256, 161), (256, 289), (256, 300), (256, 512), (256, 1000)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_attention_dkv_one_pass_equals_two_passes(hip, L, p):
-    """d = 128, >= 256 tokens: dK and dV come from ONE pass (V rows in LDS, csrc/attn.hip attn_bwd_dkv128_kernel); the
-    two-pass kernels stay selectable (flag ORBIT2_ATTN_SPLIT_DKV of orbit2_attn_bwd_ex) and must give the same bits -- odd
-    tile counts (L = 300: 5 tiles, the pair loop's sixth is past the end) and ragged tails included"""
-    B, H, d = 2, 3, 128
+def test_attention_dkv_one_pass_equals_two_passes(hip, d, L, p):
+    """dK and dV come from ONE pass at d = 128 (>= 256 tokens: V rows in LDS, csrc/attn.hip attn_bwd_dkv128_kernel) and -- round
+    3 -- at d = 256 (attn_bwd_dkv256_kernel: 32-row query tiles, one wave per SIMD); the two-pass kernels stay selectable
+    (flag ORBIT2_ATTN_SPLIT_DKV of orbit2_attn_bwd_ex) and must give the same bits -- odd tile counts (the pair loop's last
+    tile is past the end) and ragged tails included"""
+    B, H = 2, (3 if d == 128 else 2)
     g = torch.Generator().manual_seed(L)
     qkv = bf(torch.randn(B, L, 3 * H * d, generator=g) * 0.7).cuda()
     do = bf(torch.randn(B, L, H * d, generator=g)).cuda()
