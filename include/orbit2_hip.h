@@ -87,7 +87,10 @@ int orbit2_layernorm_bwd_ws_floats(int rows, int D);
  * drop_p: dropout on P (attention.py:57,69,76). */
 int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
                     uint64_t seed, void* stream);
-/* dqkv: bf16 [B, L, 3, H, d];  delta: fp32 workspace [B, H, L] */
+/* dqkv: bf16 [B, L, 3, H, d];  delta: fp32 workspace of orbit2_attn_bwd_ws_floats(B, L, H) floats (two per-row statistics
+ * tables, -lse log2(e) and -rowsum(dO o O) / dropout scale, padded per (b, h): the dK / dV kernels copy their tiles of it into
+ * LDS by LDS-DMA) */
+int64_t orbit2_attn_bwd_ws_floats(int B, int L, int H);
 int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                     void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, void* stream);
 /* The same two entries with the kernel variant as an ARGUMENT (A/B timing and the bit-equality tests of the fused

@@ -262,7 +262,8 @@ def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0, flags=0):
 def attn_bwd(qkv, out, dout, lse, B, L, H, d, drop_p=0.0, seed=0, flags=0):
     _dev(qkv, BF, "qkv"); _dev(out, BF, "out"); _dev(dout, BF, "dout"); _dev(lse, F32, "lse")
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, H, L, dtype=F32, device=qkv.device)
+    lib().orbit2_attn_bwd_ws_floats.restype = C.c_int64
+    delta = torch.empty(int(lib().orbit2_attn_bwd_ws_floats(B, L, H)), dtype=F32, device=qkv.device)
     if timer is not None:
         # algorithmic: 2x the forward's FLOPs (recompute not credited); qkv, out, dout read once, dqkv written once
         e0, e1 = timer.span("attn_bwd", 8.0 * B * H * L * L * d, 2.0 * 8 * B * L * H * d + 8.0 * B * H * L)

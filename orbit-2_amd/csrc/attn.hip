@@ -15,6 +15,9 @@
 // the transposed reads (16-byte chunk c of row r stored at chunk c ^ f(r)); tiles arrive by LDS-DMA with
 // the swizzle applied on the per-lane SOURCE address (destination is lane-linear).
 #include "tiles32.h"
+#ifndef O2_DKV256_LA
+#define O2_DKV256_LA 2      /* k-steps of LDS operands in flight in the d = 256 fused dK+dV kernel */
+#endif
 #include "../../include/orbit2_hip.h"
 
 namespace {
@@ -511,17 +514,32 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
 }
 
 // =============================================================================================
-// delta[b,h,q] = sum_d dO*O
+// per-row statistics of the backward, ready to use: ws[0][b,h,q] = -lse * log2(e), ws[1][b,h,q] = -(sum_d dO*O) / dscale
 // =============================================================================================
+// Rows are padded per (b, h) to Lp >= ceil64(L) + 64 entries, the pad holding (-1e30, 0): the dK / dV kernels copy a tile's 64
+// (or 32) entries straight into LDS by LDS-DMA -- no clamping, no conversion, no register -- and a query row past the end of the
+// sequence contributes exp2(s - 1e30) = 0.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int L, int H, int D) {
-  // one 16-lane group per (token, head) row of D elements
+                                                         const float* __restrict__ lse, float* __restrict__ ws, int B, int L,
+                                                         int H, int D, int Lp, float inv_dscale) {
+  // one 16-lane group per (batch, padded token, head) row of D elements
   const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int li = threadIdx.x & 15;
-  const int64_t nrows = (int64_t)B * L * H;
+  const int64_t nrows = (int64_t)B * Lp * H;
   if (grp >= nrows) return;
-  const bf16_t* po = o + grp * D;
-  const bf16_t* pd = dout + grp * D;
+  const int64_t tokp = grp / H;
+  const int hh = (int)(grp - tokp * H);
+  const int64_t bb = tokp / Lp;
+  const int64_t q = tokp - bb * Lp;
+  float* nlse2 = ws + ((size_t)(bb * H + hh)) * Lp + q;
+  float* ndelta = nlse2 + (size_t)B * H * Lp;
+  if (q >= L) {                                   // pad row
+    if (li == 0) { *nlse2 = -1e30f; *ndelta = 0.f; }
+    return;
+  }
+  const int64_t row = (bb * L + q) * H + hh;
+  const bf16_t* po = o + row * D;
+  const bf16_t* pd = dout + row * D;
   float s = 0.f;
   for (int c = li; c < D / 8; c += 16) {
     const u32x4 a = *reinterpret_cast<const u32x4*>(po + c * 8);
@@ -534,11 +552,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (li == 0) {
-    const int64_t tok = grp / H;
-    const int hh = (int)(grp - tok * H);
-    const int64_t bb = tok / L;
-    const int64_t q = tok - bb * L;
-    delta[((size_t)(bb * H + hh)) * L + q] = s;
+    *nlse2 = -(lse[((size_t)(bb * H + hh)) * L + q] * 1.4426950408889634f);
+    *ndelta = -(s * inv_dscale);
   }
 }
 
@@ -551,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                             unsigned thr, float dscale, uint64_t seed_arg, float opmul) {
+                                                             unsigned thr, float dscale, uint64_t seed_arg, float opmul, int Lp) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];
@@ -578,12 +593,13 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
     qf[ds] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * tstride + ds * 16 + 8 * hq), sc_log2);
     dof[ds] = *reinterpret_cast<const bf16x8*>(dorow + ds * 16 + 8 * hq);
   }
-  const size_t sidx = ((size_t)(b * H + head)) * L + qrow;
   // Q enters the S MFMAs pre-multiplied by log2(e)/sqrt(d) and the S / dP accumulators START at -lse2 / -delta of the lane's
   // row (two 16-register constant blocks, the C operands of every chain's first MFMA): S leaves the matrix pipe as the exp2
   // argument and dP as dP - delta -- no multiply and no subtraction per score element.
-  const float lse2 = lse[sidx] * 1.4426950408889634f;
-  const float dlt = DROP ? delta[sidx] / dscale : delta[sidx];   // dscale folded into the final scale
+  // (lse / delta: the ready-made tables of attn_delta_kernel, -lse log2(e) and -delta / dscale, padded row stride Lp)
+  const size_t sidx_p = ((size_t)(b * H + head)) * Lp + qrow;
+  const float lse2 = -lse[sidx_p];
+  const float dlt = -delta[sidx_p];
   // (d = 128 runs two waves per SIMD on 256 registers: only the S block fits there, dP - delta stays a subtraction)
   constexpr bool DLT_INIT = (D != 128);
   f32x16 nlse, ndlt;
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                               unsigned thr, float dscale, uint64_t seed_arg, float opmul,
-                                                              float kgrad) {
+                                                              float kgrad, int Lp) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   constexpr bool DO_DK = WHICH != 2, DO_DV = WHICH != 1;
@@ -710,22 +726,25 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
       if (DO_DV) dv[i][r] = 0.f;
     }
 
-  const size_t sbase = ((size_t)(b * H + head)) * L;
   const uint64_t bh = (uint64_t)(b * H + head);
   const uint32_t keyhash = DROP ? o2_attn_keyhash(seed, (uint32_t)(krow >> 2)) : 0u;   // this lane's key group
   const int nt = (L + 63) / 64;
+  // per-row statistics of a tile (-lse log2(e), -delta / dscale: the ready-made, padded tables of attn_delta_kernel) go
+  // global -> LDS by two 256-byte LDS-DMA pieces, in the same vmcnt stream as the tile's own pieces: no register, no conversion
+  // and -- unlike the load + convert + ds_write of rounds 1-2, whose first use of the loaded word sat at the top of the loop body
+  // -- no wait for the load's latency and for every DMA piece issued before it, once per tile (round 3: -24 % on the d = 256
+  // dK+dV kernel, profiles/r03_attn_dkv_stats_ab.txt).  The accumulators of S and dP start from these rows.
+  const size_t sbase_p = ((size_t)(b * H + head)) * Lp;
   auto stage_stats = [&](int t, int buf) {
-    if (tid < 128) {
-      const int which = tid >> 6, i = tid & 63;
-      float v;
-      if (!RAGGED || t * 64 + i < L)
-        v = which ? (DROP ? delta[sbase + t * 64 + i] / dscale : delta[sbase + t * 64 + i])
-                  : lse[sbase + t * 64 + i] * 1.4426950408889634f;
-      else
-        v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
-      sstat[(buf * 3 + which) * 64 + i] = -v;   // stored NEGATED: the S and dP accumulators start from these rows
+    if (wave < 2) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));        // the per-lane offset is rebuilt here, not kept in a register across the tile loop
+      glds4_asm((wave ? delta : lse) + sbase_p + (size_t)t * 64, (uint32_t)ln * 4u,
+                (uint32_t)(uintptr_t)LDS_PTR(float, sstat + (buf * 3 + wave) * 64));
     } else if (DROP && tid < 192) {   // dropout: hashes of the tile's 64 query rows
-      const int i = tid & 63;
+      int i = tid & 63;
+      asm volatile("" : "+v"(i));         // (rebuilt here: hoisted out of the tile loop the slot address gets spilled, and its
+                                          //  reload's vmcnt(0) drains the DMA pieces just issued)
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
     }
   };
@@ -880,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
                                                                  const float* __restrict__ delta,
                                                                  bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                                  unsigned thr, float dscale, uint64_t seed_arg, float opmul,
-                                                                 float kgrad) {
+                                                                 float kgrad, int Lp) {
   constexpr int D = 128, NW = 8;
   using C = Cfg<D>;
   constexpr int VOFF = 4 * C::TILE, SOFF = 8 * C::TILE;       // [2][Q|dO] | V rows of the workgroup | [2][lse2|delta|row hash]
@@ -921,46 +940,58 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
   // ---- LDS addresses: row fragments (k-step ds of row lane&31) and transposed fragments (head-dim block db)
-  const char* rq[C::NDS];
+  // (32-bit LDS byte addresses: one register each)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  uint32_t rq[C::NDS];
   {
     const int r = lane & 31;
 #pragma unroll
-    for (int ds = 0; ds < C::NDS; ++ds) rq[ds] = smem + r * C::RB + (((ds * 2 + hq) ^ swz<D>(r)) << 4);
+    for (int ds = 0; ds < C::NDS; ++ds) rq[ds] = lds0 + r * C::RB + (((ds * 2 + hq) ^ swz<D>(r)) << 4);
   }
   const int vwoff = VOFF + wave * 32 * C::RB;                 // this wave's 32 V rows
-  const char *t0[C::NDB], *t1[C::NDB];
+  uint32_t t0[C::NDB], t1[C::NDB];
   {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int row = 4 * hq + q, row1 = row + 8;
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) {
       const int c = db * 4 + 2 * (g & 1) + (p >> 1);
-      t0[db] = smem + row * C::RB + ((c ^ swz<D>(row)) << 4) + 8 * (p & 1);
-      t1[db] = smem + row1 * C::RB + ((c ^ swz<D>(row1)) << 4) + 8 * (p & 1);
+      t0[db] = lds0 + row * C::RB + ((c ^ swz<D>(row)) << 4) + 8 * (p & 1);
+      t1[db] = lds0 + row1 * C::RB + ((c ^ swz<D>(row1)) << 4) + 8 * (p & 1);
     }
   }
-  const float* st4 = sstat + 4 * hq;                                        // + (buf*3 + which)*64 + qb*32 + 8*g4
-  const uint32_t* sh1 = reinterpret_cast<const uint32_t*>(sstat) + 4 * hq + (lane & 3);
+  const uint32_t st4 = lds0 + SOFF + 16 * hq;                               // + ((buf*3 + which)*64 + qb*32 + 8*g4) * 4
+  const uint32_t sh1 = lds0 + SOFF + (4 * hq + (lane & 3)) * 4;
+  auto ld128 = [](uint32_t a_) { return *(const __attribute__((address_space(3))) bf16x8*)(a_); };
+  auto ldf4 = [](uint32_t a_) { return *(const __attribute__((address_space(3))) f32x4*)(a_); };
+  auto ldtr = [](uint32_t a0, uint32_t a1) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
 
-  const size_t sbase = ((size_t)(b * H + head)) * L;
   const uint64_t bh = (uint64_t)(b * H + head);
   const uint32_t keyhash = DROP ? o2_attn_keyhash(seed, (uint32_t)(krow >> 2)) : 0u;   // this lane's key group
   const uint32_t kbyte = 8 * (krow & 3);
   const uint32_t bmask = 0xffu << kbyte, thrs = thr << kbyte;
   const int nt = (L + 63) / 64;
   const int nt2 = RAGGED ? ((nt + 1) & ~1) : nt;          // whole pairs of tiles (a tile past the end contributes nothing)
+  // per-row statistics of a tile (-lse log2(e), -delta / dscale: the ready-made, padded tables of attn_delta_kernel) go
+  // global -> LDS by two 256-byte LDS-DMA pieces, in the same vmcnt stream as the tile's own pieces: no register, no conversion
+  // and -- unlike the load + convert + ds_write of rounds 1-2, whose first use of the loaded word sat at the top of the loop body
+  // -- no wait for the load's latency and for every DMA piece issued before it, once per tile (round 3: -24 % on the d = 256
+  // dK+dV kernel, profiles/r03_attn_dkv_stats_ab.txt).  The accumulators of S and dP start from these rows.
+  const size_t sbase_p = ((size_t)(b * H + head)) * Lp;
   auto stage_stats = [&](int t, int buf) {
-    if (tid < 128) {
-      const int which = tid >> 6, i = tid & 63;
-      float v;
-      if (!RAGGED || t * 64 + i < L)
-        v = which ? (DROP ? delta[sbase + t * 64 + i] / dscale : delta[sbase + t * 64 + i])
-                  : lse[sbase + t * 64 + i] * 1.4426950408889634f;
-      else
-        v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
-      sstat[(buf * 3 + which) * 64 + i] = -v;   // stored NEGATED: the S and dP accumulators start from these rows
+    if (wave < 2) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));        // the per-lane offset is rebuilt here, not kept in a register across the tile loop
+      glds4_asm((wave ? delta : lse) + sbase_p + (size_t)t * 64, (uint32_t)ln * 4u,
+                (uint32_t)(uintptr_t)LDS_PTR(float, sstat + (buf * 3 + wave) * 64));
     } else if (DROP && tid < 192) {   // dropout: hashes of the tile's 64 query rows
-      const int i = tid & 63;
+      int i = tid & 63;
+      asm volatile("" : "+v"(i));         // (rebuilt here: hoisted out of the tile loop the slot address gets spilled, and its
+                                          //  reload's vmcnt(0) drains the DMA pieces just issued)
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
     }
   };
@@ -987,24 +1018,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
       f32x16 s, dp;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 0) * 64 + qb * 32 + 8 * g4);
-        const f32x4 c4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 1) * 64 + qb * 32 + 8 * g4);
+        const f32x4 a4 = ldf4(st4 + ((CUR * 3 + 0) * 64 + qb * 32 + 8 * g4) * 4);
+        const f32x4 c4 = ldf4(st4 + ((CUR * 3 + 1) * 64 + qb * 32 + 8 * g4) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[4 * g4 + e] = a4[e]; dp[4 * g4 + e] = c4[e]; }
       }
       int vw = vwoff;
       asm volatile("" : "+s"(vw));          // keep the 8 V addresses out of registers: one v_add per read instead
       // one k-step of operands in flight (12 registers), pinned: hipcc otherwise prefetches all 24 fragments (96 registers)
-      bf16x8 qf = *reinterpret_cast<const bf16x8*>(rq[0] + QO + qb * 32 * C::RB);
-      bf16x8 dof = *reinterpret_cast<const bf16x8*>(rq[0] + DOO + qb * 32 * C::RB);
-      bf16x8 vf = *reinterpret_cast<const bf16x8*>(rq[0] + vw);
+      bf16x8 qf = ld128(rq[0] + QO + qb * 32 * C::RB);
+      bf16x8 dof = ld128(rq[0] + DOO + qb * 32 * C::RB);
+      bf16x8 vf = ld128(rq[0] + vw);
 #pragma unroll
       for (int ds = 0; ds < C::NDS; ++ds) {
         bf16x8 qn = qf, don = dof, vn = vf;
         if (ds + 1 < C::NDS) {
-          qn = *reinterpret_cast<const bf16x8*>(rq[ds + 1] + QO + qb * 32 * C::RB);
-          don = *reinterpret_cast<const bf16x8*>(rq[ds + 1] + DOO + qb * 32 * C::RB);
-          vn = *reinterpret_cast<const bf16x8*>(rq[ds + 1] + vw);
+          qn = ld128(rq[ds + 1] + QO + qb * 32 * C::RB);
+          don = ld128(rq[ds + 1] + DOO + qb * 32 * C::RB);
+          vn = ld128(rq[ds + 1] + vw);
         }
         s = MFMA32(qf, kf[ds], s);
         dp = MFMA32(dof, vf, dp);
@@ -1015,13 +1046,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
       uint32_t hmine[4] = {0u, 0u, 0u, 0u};
       if (DROP) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) hmine[g4] = o2_attn_mix(sh1[(CUR * 3 + 2) * 64 + qb * 32 + 8 * g4], keyhash);
+        for (int g4 = 0; g4 < 4; ++g4) hmine[g4] = o2_attn_mix(*(const __attribute__((address_space(3))) uint32_t*)(sh1 + ((CUR * 3 + 2) * 64 + qb * 32 + 8 * g4) * 4), keyhash);
       }
       u32x4 pfw[2], dsw[2];     // P after dropout (for dV) and dS (for dK) as the operands of k-steps ss = 0, 1
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 ndl4 = {0.f, 0.f, 0.f, 0.f};
-        if (DROP) ndl4 = *reinterpret_cast<const f32x4*>(st4 + (CUR * 3 + 1) * 64 + qb * 32 + 8 * g4);   // -delta
+        if (DROP) ndl4 = ldf4(st4 + ((CUR * 3 + 1) * 64 + qb * 32 + 8 * g4) * 4);   // -delta
         float pv[4], dsv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1049,8 +1080,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
       {
         auto trd = [&](int j, int off) {     // j = ss*4 + db
           const int ro = (qb * 32 + (j >> 2) * 16) * C::RB + off;
-          const bf16x4 lo = lds_tr4(t0[j & 3] + ro), hi = lds_tr4(t1[j & 3] + ro);
-          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          return ldtr(t0[j & 3] + ro, t1[j & 3] + ro);
         };
         bf16x8 fd = trd(0, DOO), fq = trd(0, QO);
 #pragma unroll
@@ -1110,7 +1140,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
                                                                  const float* __restrict__ delta,
                                                                  bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                                  unsigned thr, float dscale, uint64_t seed_arg, float opmul,
-                                                                 float kgrad) {
+                                                                 float kgrad, int Lp) {
   constexpr int D = 256, NW = 4, TR = 32;                    // TR: query rows per staged tile
   using C = Cfg<D>;
   constexpr int TILE = TR * C::RB;                           // 16 KB
@@ -1135,15 +1165,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
   float* sstat = reinterpret_cast<float*>(smem + SOFF);
 
   // stage ROWS rows (a multiple of 2 * NW) of a [rows][256] bf16 matrix: 1-KiB pieces of two rows each, swizzled source
+  // (inline-asm LDS-DMA, common.h: the compiler drains the builtin form in the middle of the tile)
   auto stage_rows = [&](const bf16_t* base, size_t stride, char* tile, int rows, int nvalid) {
     const int pieces = rows / 2 / NW;                        // per wave
+    const uint32_t dst0 = (uint32_t)(uintptr_t)LDS_PTR(char, tile);
     for (int t = 0; t < pieces; ++t) {
       const int i = wave * pieces + t;
       const int row = i * 2 + lane / 32;
       const int c = (lane % 32) ^ swz<D>(row);
       const int rsrc = (!RAGGED || row < nvalid) ? row : nvalid - 1;
       const uint32_t off = ((uint32_t)rsrc * (uint32_t)stride + (uint32_t)(c * 8)) * 2u;
+#ifdef O2_DKV256_BUILTIN_DMA
       glds16(reinterpret_cast<const char*>(base) + off, tile + i * 1024);
+#else
+      glds16_asm(base, off, dst0 + i * 1024);
+#endif
     }
   };
 
@@ -1192,25 +1228,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
   const uint32_t st4 = lds0 + SOFF + 16 * hq;                               // + ((buf*3 + which)*TR + 8*g4) * 4
   const uint32_t sh1 = lds0 + SOFF + (4 * hq + (lane & 3)) * 4;
 
-  const size_t sbase = ((size_t)(b * H + head)) * L;
   const uint64_t bh = (uint64_t)(b * H + head);
   const uint32_t keyhash = DROP ? o2_attn_keyhash(seed, (uint32_t)(krow >> 2)) : 0u;   // this lane's key group
   const uint32_t kbyte = 8 * (krow & 3);
   const uint32_t bmask = 0xffu << kbyte, thrs = thr << kbyte;
   const int nt = (L + TR - 1) / TR;
   const int nt2 = (nt + 1) & ~1;                            // whole pairs of tiles (a tile past the end contributes nothing)
+  // per-row statistics (see attn_bwd_dkv128_kernel): two LDS-DMA pieces of TR dwords from the ready-made, padded tables
+  const size_t sbase_p = ((size_t)(b * H + head)) * Lp;
   auto stage_stats = [&](int t, int buf) {
-    if (tid < 2 * TR) {
-      const int which = tid / TR, i = tid % TR;
-      float v;
-      if (t * TR + i < L)
-        v = which ? (DROP ? delta[sbase + t * TR + i] / dscale : delta[sbase + t * TR + i])
-                  : lse[sbase + t * TR + i] * 1.4426950408889634f;
-      else
-        v = which ? 0.f : 1e30f;   // query rows past the end: exp2(s - 1e30) = 0, they contribute nothing
-      sstat[(buf * 3 + which) * TR + i] = -v;   // stored NEGATED: the S and dP accumulators start from these rows
-    } else if (DROP && tid < 3 * TR) {   // dropout: hashes of the tile's query rows
-      const int i = tid % TR;
+    if (wave < 2) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      if (ln < TR)
+        glds4_asm((wave ? delta : lse) + sbase_p + (size_t)t * TR, (uint32_t)ln * 4u,
+                  (uint32_t)(uintptr_t)LDS_PTR(float, sstat + (buf * 3 + wave) * TR));
+    } else if (DROP && tid < 128 + TR) {   // dropout: hashes of the tile's query rows
+      int i = tid - 128;
+      asm volatile("" : "+v"(i));
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * TR + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * TR + i));
     }
   };
@@ -1241,15 +1276,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
     uint32_t vw = vwoff;
     asm volatile("" : "+s"(vw));          // keep the V addresses out of registers: one v_add per read instead
     auto rowaddr = [&](int ds) { return rq[ds & 7] + (ds >> 3) * 256; };
-    bf16x8 qf = ld128(rowaddr(0) + QO), dof = ld128(rowaddr(0) + DOO), vf = ld128(rowaddr(0) + vw);
+    // O2_LA k-steps of operands in flight (one wave per SIMD: nobody else covers an LDS read's latency), pinned
+    constexpr int LA = O2_DKV256_LA;
+    bf16x8 qr[LA + 1], dr[LA + 1], vr[LA + 1];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) { qr[i] = ld128(rowaddr(i) + QO); dr[i] = ld128(rowaddr(i) + DOO); vr[i] = ld128(rowaddr(i) + vw); }
 #pragma unroll
     for (int ds = 0; ds < C::NDS; ++ds) {
-      bf16x8 qn = qf, don = dof, vn = vf;
-      if (ds + 1 < C::NDS) { qn = ld128(rowaddr(ds + 1) + QO); don = ld128(rowaddr(ds + 1) + DOO); vn = ld128(rowaddr(ds + 1) + vw); }
-      s = MFMA32(qf, kf[ds], s);
-      dp = MFMA32(dof, vf, dp);
+      if (ds + LA < C::NDS) {
+        constexpr int dummy = 0; (void)dummy;
+        qr[(ds + LA) % (LA + 1)] = ld128(rowaddr(ds + LA) + QO);
+        dr[(ds + LA) % (LA + 1)] = ld128(rowaddr(ds + LA) + DOO);
+        vr[(ds + LA) % (LA + 1)] = ld128(rowaddr(ds + LA) + vw);
+      }
+      s = MFMA32(qr[ds % (LA + 1)], kf[ds], s);
+      dp = MFMA32(dr[ds % (LA + 1)], vr[ds % (LA + 1)], dp);
       __builtin_amdgcn_sched_barrier(0);
-      qf = qn; dof = don; vf = vn;
     }
     __builtin_amdgcn_sched_barrier(0);
     uint32_t hmine[4] = {0u, 0u, 0u, 0u};
@@ -1293,15 +1335,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
         const uint32_t ro = (ss * 16) * C::RB + off + (db >> 2) * 256;
         return ldtr(t0[db & 3] + ro, t1[db & 3] + ro);
       };
-      bf16x8 fd = trd(0, DOO), fq = trd(0, QO);
+      constexpr int LB = O2_DKV256_LA;
+      bf16x8 fdr[LB + 1], fqr[LB + 1];
+#pragma unroll
+      for (int i = 0; i < LB; ++i) { fdr[i] = trd(i, DOO); fqr[i] = trd(i, QO); }
 #pragma unroll
       for (int j = 0; j < 2 * C::NDB; ++j) {
-        bf16x8 fdn = fd, fqn = fq;
-        if (j + 1 < 2 * C::NDB) { fdn = trd(j + 1, DOO); fqn = trd(j + 1, QO); }
-        dv[j % C::NDB] = MFMA32(fd, pf[j / C::NDB], dv[j % C::NDB]);     // dV^T += dO^T . P
-        dk[j % C::NDB] = MFMA32(fq, dsf[j / C::NDB], dk[j % C::NDB]);    // dK^T += Q^T . dS
+        if (j + LB < 2 * C::NDB) { fdr[(j + LB) % (LB + 1)] = trd(j + LB, DOO); fqr[(j + LB) % (LB + 1)] = trd(j + LB, QO); }
+        dv[j % C::NDB] = MFMA32(fdr[j % (LB + 1)], pf[j / C::NDB], dv[j % C::NDB]);     // dV^T += dO^T . P
+        dk[j % C::NDB] = MFMA32(fqr[j % (LB + 1)], dsf[j / C::NDB], dk[j % C::NDB]);    // dK^T += Q^T . dS
         __builtin_amdgcn_sched_barrier(0);
-        fd = fdn; fq = fqn;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1408,39 +1451,46 @@ extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B,
 
 template <int DV, bool DR, bool RG, int NW>
 static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta, bf16_t* dq_, int B, int L,
-                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s, int flags) {
+                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s, int flags, int Lp) {
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
   const bool pre = (flags & ORBIT2_ATTN_Q_PRESCALED) != 0;
   const float opmul = pre ? 1.0f : scale * 1.4426950408889634f, kgrad = pre ? 0.6931471805599453f : scale;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                     seed, opmul);
+                     seed, opmul, Lp);
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed, opmul, kgrad);
+                       dscale, seed, opmul, kgrad, Lp);
   } else if (DV == 256 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {             // one pass at one wave per SIMD (interm_10b)
     hipLaunchKernelGGL((attn_bwd_dkv256_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                       seed, opmul, kgrad);
+                       seed, opmul, kgrad, Lp);
   } else if (DV == 128 && NW == 8 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {   // one pass, V rows in LDS
     hipLaunchKernelGGL((attn_bwd_dkv128_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                       seed, opmul, kgrad);
+                       seed, opmul, kgrad, Lp);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 1, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed, opmul, kgrad);
+                       dscale, seed, opmul, kgrad, Lp);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 2, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed, opmul, kgrad);
+                       dscale, seed, opmul, kgrad, Lp);
   }
 }
 template <int DV, int NW>
 static void launch_bwd_r(bool drop, bool ragged, const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta,
                          bf16_t* dq_, int B, int L, int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s,
-                         int flags) {
+                         int flags, int Lp) {
   if (drop) {
-    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
-    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
   } else {
-    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
-    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
   }
+}
+
+static int attn_lpad(int L) { return ((L + 63) / 64) * 64 + 64; }     // padded row stride of the statistics tables
+
+extern "C" int64_t orbit2_attn_bwd_ws_floats(int B, int L, int H) {
+  if (B <= 0 || L <= 0 || H <= 0) return 0;
+  return (int64_t)2 * B * H * attn_lpad(L);
 }
 
 extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
@@ -1458,22 +1508,26 @@ extern "C" int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* 
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t nrows = (int64_t)B * L * H;
+  // per-row statistics tables (attn_delta_kernel): delta = workspace of orbit2_attn_bwd_ws_floats(B, L, H) floats
+  const int Lp = attn_lpad(L);
+  float* ws0 = delta;
+  float* ws1 = delta + (size_t)B * H * Lp;
+  const int64_t nrows = (int64_t)B * Lp * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, s,
-                     (const bf16_t*)out, (const bf16_t*)dout, delta, B, L, H, d);
+                     (const bf16_t*)out, (const bf16_t*)dout, lse, delta, B, L, H, d, Lp, 1.0f / dscale);
   O2_CHECK_LAUNCH();
   const bf16_t* q_ = (const bf16_t*)qkv;
   const bf16_t* do_ = (const bf16_t*)dout;
   bf16_t* dq_ = (bf16_t*)dqkv;
   const int nw = attn_waves(L, d, flags);
   const bool ragged = (L % (nw * 32)) != 0;
-  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
   else if (d == 128) {
-    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
-    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
   } else {
-    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
-    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags);
+    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
   }
   O2_CHECK_LAUNCH();
   return O2_OK;

@@ -31,6 +31,33 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GLB_PTR(void, gsrc), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
+// 4-byte LDS-DMA: lane l's dword lands at (wave-uniform base) + 4 l  (per-row statistics tables of the attention backward)
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(void, gsrc), LDS_PTR(void, lds_wave_base), 4, 0, 0);
+}
+// The same LDS-DMA as an inline-asm statement the compiler cannot see into (saddr form: wave-uniform 64-bit base + 32-bit
+// per-lane byte offset).  hipcc models the builtin above as an LDS write pending on vmcnt and, when it cannot prove that an LDS
+// read touches other bytes (the other stage of the same __shared__ array, addressed through a lane-dependent register), puts
+// s_waitcnt vmcnt(0) in front of the read: a tile prefetched at the top of a loop body is drained in the MIDDLE of that body
+// (in front of the first ds_read_b64_tr_b16) instead of at its end.  With this form the kernel owns the ordering -- its own
+// s_waitcnt vmcnt(0) + s_barrier before the first read of the slot -- and the compiler's vmcnt arithmetic stays safe: it can only
+// under-count the operations younger than one of ITS loads, i.e. wait longer than needed.  M0 (the DMA's LDS base) is written
+// and restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* gbase_uniform, uint32_t lane_byte_off, uint32_t lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(gbase_uniform), "s"(lds_dst_uniform)
+               : "memory");
+}
+// 4-byte form of the same (per-row statistics tables): lane l's dword from gbase + 4 l lands at lds_dst + 4 l
+__device__ __forceinline__ void glds4_asm(const void* gbase_uniform, uint32_t lane_byte_off, uint32_t lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(gbase_uniform), "s"(lds_dst_uniform)
+               : "memory");
+}
 // transposed 4x16 block read (ds_read_b64_tr_b16): lane i of a 16-lane group receives column i.
 __device__ __forceinline__ bf16x4 lds_tr4(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, lds_addr));

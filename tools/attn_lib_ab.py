@@ -33,7 +33,7 @@ for (H, L, d, Bx) in [(24, 8192, 128, B), (16, 4096, 64, B), (32, 4096, 256, max
         r = {}
         for k, lib in libs.items():
             out = torch.empty(Bx, L, H * d, dtype=BF, device="cuda"); lse = torch.empty(Bx, H, L, dtype=F32, device="cuda")
-            delta = torch.empty_like(lse); dqkv = torch.empty_like(qkv)
+            delta = torch.empty(2 * Bx * H * ((L + 63) // 64 * 64 + 64), dtype=F32, device="cuda"); dqkv = torch.empty_like(qkv)   # >= orbit2_attn_bwd_ws_floats
             fwd(lib, qkv, out, lse, Bx, L, H, d, p); bwd(lib, qkv, out, do, lse, delta, dqkv, Bx, L, H, d, p)
             r[k] = (out, lse, delta, dqkv)
         torch.cuda.synchronize()

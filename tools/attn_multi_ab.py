@@ -12,6 +12,9 @@ BF, F32 = torch.bfloat16, torch.float32
 P = lambda t: C.c_void_p(t.data_ptr())
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 H, L, d = 24, 8192, 128
+if "--shape" in sys.argv:        # --shape B H L d   (e.g. the interm_10b shape: 1 32 8192 256)
+    i = sys.argv.index("--shape")
+    B, H, L, d = (int(v) for v in sys.argv[i + 1:i + 5])
 qkv = (torch.randn(B, L, 3 * H * d, device="cuda") * 0.7).to(BF)
 do = torch.randn(B, L, H * d, device="cuda").to(BF)
 def t(f, n=4):
@@ -25,7 +28,7 @@ for p in (0.1, 0.0):
     st = {}
     for name, lib in libs:
         out = torch.empty(B, L, H * d, dtype=BF, device="cuda"); lse = torch.empty(B, H, L, dtype=F32, device="cuda")
-        delta = torch.empty_like(lse); dq = torch.empty_like(qkv)
+        delta = torch.empty(2 * B * H * ((L + 63) // 64 * 64 + 64), dtype=F32, device="cuda"); dq = torch.empty_like(qkv)   # >= orbit2_attn_bwd_ws_floats
         st[name] = (out, lse, delta, dq)
     def fwd(lib, s): assert lib.orbit2_attn_fwd(P(qkv), P(s[0]), P(s[1]), B, L, H, d, C.c_float(p), C.c_uint64(11), S()) == 0
     def bwd(lib, s): assert lib.orbit2_attn_bwd(P(qkv), P(s[0]), P(do), P(s[1]), P(s[2]), P(s[3]), B, L, H, d, C.c_float(p), C.c_uint64(11), S()) == 0
