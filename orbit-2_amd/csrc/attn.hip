@@ -343,8 +343,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
       const int tt = T * KT + j;
       if (tt < nt) {
         char* nk = smem + buf * STAGE + j * 2 * C::TILE;
-        stage64<D, RAGGED, NW>(kbase + (size_t)tt * 64 * tstride, tstride, nk, wave, lane, L - tt * 64);
-        stage64<D, RAGGED, NW>(vbase + (size_t)tt * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - tt * 64);
+        stage64<D, RAGGED, NW, (D >= 128)>(kbase + (size_t)tt * 64 * tstride, tstride, nk, wave, lane, L - tt * 64);
+        stage64<D, RAGGED, NW, (D >= 128)>(vbase + (size_t)tt * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - tt * 64);
         if (DROP) stage_keyhash(skh[buf] + j * 16, seed, tt, tid);
       }
     }
@@ -614,8 +614,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
   const int nt = (L + 63) / 64;
-  stage64<D, RAGGED, NW>(kbase, tstride, smem, wave, lane, L);
-  stage64<D, RAGGED, NW>(vbase, tstride, smem + C::TILE, wave, lane, L);
+  stage64<D, RAGGED, NW, DROP>(kbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED, NW, DROP>(vbase, tstride, smem + C::TILE, wave, lane, L);
   if (DROP) stage_keyhash(skh[0], seed, 0, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -625,8 +625,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
     const char* sv = sk + C::TILE;
     if (t + 1 < nt) {
       char* nk = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D, RAGGED, NW>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
-      stage64<D, RAGGED, NW>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW, DROP>(kbase + (size_t)(t + 1) * 64 * tstride, tstride, nk, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW, DROP>(vbase + (size_t)(t + 1) * 64 * tstride, tstride, nk + C::TILE, wave, lane, L - (t + 1) * 64);
       if (DROP) stage_keyhash(skh[cur ^ 1], seed, t + 1, tid);
     }
 #pragma unroll
@@ -748,8 +748,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
       reinterpret_cast<uint32_t*>(sstat)[(buf * 3 + 2) * 64 + i] = o2_attn_rowhash(seed, bh * (uint64_t)L + (uint64_t)(t * 64 + i));
     }
   };
-  stage64<D, RAGGED, NW>(qbase, tstride, smem, wave, lane, L);
-  stage64<D, RAGGED, NW>(dobase, ostride, smem + C::TILE, wave, lane, L);
+  stage64<D, RAGGED, NW, DROP>(qbase, tstride, smem, wave, lane, L);
+  stage64<D, RAGGED, NW, DROP>(dobase, ostride, smem + C::TILE, wave, lane, L);
   stage_stats(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -759,8 +759,8 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
     const char* sdo = sq + C::TILE;
     if (t + 1 < nt) {
       char* nq = smem + (cur ^ 1) * 2 * C::TILE;
-      stage64<D, RAGGED, NW>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane, L - (t + 1) * 64);
-      stage64<D, RAGGED, NW>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW, DROP>(qbase + (size_t)(t + 1) * 64 * tstride, tstride, nq, wave, lane, L - (t + 1) * 64);
+      stage64<D, RAGGED, NW, DROP>(dobase + (size_t)(t + 1) * 64 * ostride, ostride, nq + C::TILE, wave, lane, L - (t + 1) * 64);
       stage_stats(t + 1, cur ^ 1);
     }
     const float* s_lse = sstat + (cur * 3 + 0) * 64;

@@ -26,7 +26,8 @@ __device__ __forceinline__ int swz(int row) {
 
 // stage a [64 rows][D] tile; rows are tokens tok0..tok0+63 of one head: src(row) = base + row*stride
 // (rows >= nvalid are read from row nvalid-1: ragged sequence lengths never touch memory outside the tensor)
-template <int D, bool RAGGED, int NW = 4>     // NW: waves of the workgroup sharing the staging (4 or 8)
+// ASM: issue the pieces as inline-asm LDS-DMA (below); chosen per kernel by measurement
+template <int D, bool RAGGED, int NW = 4, bool ASM = false>     // NW: waves of the workgroup sharing the staging (4 or 8)
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t stride, char* tile, int wave,
                                         int lane, int nvalid) {
   using C = Cfg<D>;
@@ -41,7 +42,15 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, size_t 
     const int rsrc = (!RAGGED || row < nvalid) ? row : nvalid - 1;
     // 32-bit per-lane byte offset on a wave-uniform base (saddr form): half the address registers of a 64-bit pointer
     const uint32_t off = ((uint32_t)rsrc * (uint32_t)stride + (uint32_t)(c * 8)) * 2u;
-    glds16(reinterpret_cast<const char*>(base) + off, tile + i * 1024);
+    // ASM = inline-asm LDS-DMA (common.h: glds16_asm).  With the builtin, hipcc cannot tell the ring slot being filled from
+    // the one being read (run-time stage index, lane-dependent read addresses) and puts s_waitcnt vmcnt(0) in front of the next
+    // LDS read: in the dQ kernel that is the FIRST read of the loop body, right behind the prefetch it has just issued -- the
+    // next tile's fetch and this tile's compute do not overlap within a wave.  With the asm form the kernels' own s_waitcnt
+    // vmcnt(0) + s_barrier at the end of every tile order the DMA against its readers.  Which form is faster is decided by
+    // what hipcc makes of the rest of the loop (round 3, per kernel, profiles/r03_attn_dma_asm_ab.txt: dQ with dropout -7.5 %,
+    // the no-dropout forward -1...-10 % with the asm form; the dropout forward +6 %, the fused dK+dV passes +2...4 % SLOWER).
+    if constexpr (ASM) glds16_asm(base, off, (uint32_t)(uintptr_t)LDS_PTR(char, tile) + i * 1024);
+    else glds16(reinterpret_cast<const char*>(base) + off, tile + i * 1024);
   }
 }
 
