@@ -481,18 +481,26 @@ def main():
                 traffic_attn = {k: tj[k]["hbm_bytes_per_launch"] for k in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv") if k in tj}
         except Exception as e:
             traffic_note = "no usable profiles/%s (%s)" % (TRAFFIC_JSON, type(e).__name__)
-        split = None       # Infinity-Cache hits vs HBM reads inside that counter traffic (mean L2-miss latency, tools/mall_probe.py)
+        split = None       # Infinity-Cache hits vs HBM reads inside that counter traffic (mean L2-miss latency of the step's kernels)
         try:
             mj = json.load(open(os.path.join(ROOT, "profiles", MALL_JSON)))
-            share = {k: v["infinity_cache_hit_share_est"] for k, v in mj.items() if isinstance(v, dict) and "gemm" in k
+            share = {k: v["infinity_cache_hit_share_est"] for k, v in mj.items() if isinstance(v, dict) and "gemm256t" in k
                      and "infinity_cache_hit_share_est" in v}
             if share and traffic is not None:
-                lo = min(share.values())
+                fam = {"gemm_8phase_single": min(v for k, v in share.items() if "grouped" not in k),
+                       "gemm_8phase_grouped_dw": min([v for k, v in share.items() if "grouped" in k] or [0.0])}
+                num = den = 0.0
+                for f, sh in fam.items():
+                    if f in tj:                      # per-family counter traffic x (1 - Infinity-Cache share of its reads)
+                        n = tj[f]["launches"]
+                        num += n * (tj[f]["fetch_bytes_per_launch"] * (1.0 - sh) + tj[f]["write_bytes_per_launch"])
+                        den += n
                 split = {"infinity_cache_hit_share_of_reads": share,
-                         "hbm_bytes_per_launch_estimate": traffic * (1.0 - lo),       # NOT floored: may read below the algorithmic bytes
-                         "calibration": mj.get("_calibration"),
+                         "hbm_bytes_per_launch_estimate": (num / den) if den else None,    # NOT floored at the algorithmic bytes
+                         "calibration_cycles": mj.get("_calibration"),
                          "method": "mean L2-miss latency (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ) of the kernels INSIDE the bench step, "
-                                   "interpolated between calibration streams (L2-resident, Infinity-Cache-resident, HBM), profiles/"
+                                   "interpolated between an Infinity-Cache-hit stream and an HBM stream measured lightly loaded and "
+                                   "saturating (the lower share is used), per kernel family; writes counted in full; profiles/"
                                    + MALL_JSON}
         except Exception:
             split = None

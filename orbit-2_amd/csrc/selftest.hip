@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const u32x4* __restrict
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * INF; i + INF <= n16; i += stride) {
     u32x4 v[INF];
 #pragma unroll
-    for (int j = 0; j < INF; ++j) v[j] = __builtin_nontemporal_load(buf + i + j);
+    for (int j = 0; j < INF; ++j) v[j] = buf[i + j];        // plain loads: a non-temporal load would not allocate in the Infinity Cache
 #pragma unroll
     for (int j = 0; j < INF; ++j) acc ^= v[j];
   }
