@@ -262,7 +262,10 @@ def main():
             scheduler.step()
             if world_rank == 0:
                 print("epoch: ", epoch, " epoch_loss ", float(epoch_loss), flush=True)
-            model_states, optimizer_states = eng.state_dict(), optimizer.state_dict()     # collective when sharded
+            if getattr(eng, "shard_params", False):      # assembled unit by unit onto the host: no full fp32 model + moments on the GPU
+                model_states, optimizer_states = eng.state_dict(offload_to_cpu=True), optimizer.state_dict(offload_to_cpu=True)
+            else:
+                model_states, optimizer_states = eng.state_dict(), optimizer.state_dict()     # collective when the optimizer is sharded
             if world_rank < tp:            # one file per tensor-parallel rank of the first group (reference :778-790)
                 os.makedirs("checkpoints/climate", exist_ok=True)
                 torch.save({"epoch": epoch, "model_state_dict": model_states,

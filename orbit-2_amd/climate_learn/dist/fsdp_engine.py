@@ -542,9 +542,13 @@ class HipFullyShardedDataParallel(nn.Module):
         return full
 
     # ---- checkpoints: the full fp32 state dict is assembled / cut unit by unit -----------------------------------------------
-    def state_dict(self, *a, **k):
-        """every rank gets the full fp32 state dict with the reference's key names (collective)"""
+    def state_dict(self, *a, offload_to_cpu: bool = False, **k):
+        """every rank gets the full fp32 state dict with the reference's key names (collective).  offload_to_cpu: assemble it
+        unit by unit onto the HOST (what the driver saves): at most one gathered unit lives on the GPU at a time, instead of 4
+        bytes per parameter of the whole model (38 GB for interm_10b) next to the sharded state it was sharded to avoid."""
         sd = self.module.state_dict(*a, **k)
+        if offload_to_cpu:
+            sd = type(sd)((kk, v.cpu()) for kk, v in sd.items())
         names = {id(p): n for n, p in self.module.named_parameters()}
         for u in self.units:
             if not u.n:
@@ -555,7 +559,9 @@ class HipFullyShardedDataParallel(nn.Module):
                 c0 = self.rank * u.ck
                 full = self.gather_range(self.flat32[u.res32 + c0:u.res32 + c0 + u.ck].clone())
             for p, off, kk in u.members:
-                sd[names[id(p)]] = full[off:off + kk].view(p.shape).clone()
+                v = full[off:off + kk].view(p.shape)
+                sd[names[id(p)]] = v.cpu() if offload_to_cpu else v.clone()
+            del full
         return sd
 
     def load_state_dict(self, sd, strict: bool = True, **k):

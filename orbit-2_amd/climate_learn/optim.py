@@ -82,16 +82,19 @@ class HipAdamW(torch.optim.Optimizer):
     def _params(self):
         return [p for g in self.param_groups for p in g["params"]]
 
-    def _moments_per_param(self, st):
+    def _moments_per_param(self, st, to_cpu: bool = False):
         """{id(param): tensor of the parameter's shape} from a moment buffer laid out like the engine's optimizer segments
-        (a segment that is a rank's 1/N chunk of a range is all-gathered first: a collective in the sharded modes)"""
+        (a segment that is a rank's 1/N chunk of a range is all-gathered first: a collective in the sharded modes).
+        to_cpu: every gathered range goes to the host before the next one is gathered (checkpoints of sharded engines)"""
         out = {}
         for sg in self.engine.opt_segments:
             rng = st[sg["os"]:sg["os"] + sg["n"]]
             if sg["gather"]:
                 rng = self.engine.gather_range(rng)
             for p, off, k in sg["members"]:
-                out[id(p)] = rng[off:off + k].view(p.shape)
+                v = rng[off:off + k].view(p.shape)
+                out[id(p)] = v.cpu() if to_cpu else v
+            del rng
         return out
 
     def _load_moments_per_param(self, st, per_param):
@@ -106,7 +109,7 @@ class HipAdamW(torch.optim.Optimizer):
                     full[off:off + k].copy_(t.reshape(-1).to(st.device, F32))
             st[sg["os"]:sg["os"] + n].copy_(full[e.rank * n:(e.rank + 1) * n] if sg["gather"] else full)
 
-    def state_dict(self):
+    def state_dict(self, offload_to_cpu: bool = False):
         if self.engine is None:
             sd = super().state_dict()
             for st in sd["state"].values():                     # torch key names for the un-managed path too
@@ -115,7 +118,7 @@ class HipAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(float(self._step))
             sd["orbit2"] = {"step": self._step, "format": 2}
             return sd
-        pm, pv = self._moments_per_param(self.m), self._moments_per_param(self.v)
+        pm, pv = self._moments_per_param(self.m, offload_to_cpu), self._moments_per_param(self.v, offload_to_cpu)
         state, idx = {}, []
         for i, p in enumerate(self._params()):
             state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": pm[id(p)], "exp_avg_sq": pv[id(p)]}

@@ -413,9 +413,13 @@ def _worker_fsdp(rank, world, port, q):
         fs.load_state_dict(sd2)
         sd3 = fs.state_dict()
         assert all(torch.equal(sd3[k], sd2[k]) for k in sd2)
+        sd4 = fs.state_dict(offload_to_cpu=True)     # the driver's checkpoint path: assembled unit by unit onto the host
+        assert all(v.device.type == "cpu" and torch.equal(v, sd2[k].cpu()) for k, v in sd4.items())
         opt = cl.load_optimizer(fs, "adamw", {"lr": 5e-4, "betas": (0.9, 0.99), "weight_decay": 1e-5})
         assert opt.m.numel() == fs.opt_state_size < sum(p.numel() for p in m_fs.parameters())
         opt._load_moments_per_param(opt.m, {id(p): torch.full(p.shape, float(i)) for i, p in enumerate(m_fs.parameters())})
+        osd_cpu = opt.state_dict(offload_to_cpu=True)
+        assert all(st["exp_avg"].device.type == "cpu" for st in osd_cpu["state"].values())
         osd = opt.state_dict()
         for i, p in enumerate(m_fs.parameters()):
             assert torch.all(osd["state"][i]["exp_avg"] == float(i)) and osd["state"][i]["exp_avg"].shape == p.shape
