@@ -662,6 +662,228 @@ __global__ __launch_bounds__(512, 2) void gemm256t_grouped_kernel(GArgs g) {
   gemm256t_tile<A_KC, B_KC>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
 }
 
+// ==========================================================================================
+// 256x256x64 tile, 256 threads = 4 waves, ONE wave per SIMD with the whole register file: a wave owns a 128 x 128 quadrant
+// (8 x 8 blocks of v_mfma_f32_16x16x32_bf16 = 256 accumulator registers a[0:255]), 128 MFMAs per K-tile fed by 32
+// ds_read_b128 (0.25 reads per MFMA against 0.375 in the 8-wave kernel) and 16 LDS-DMA pieces per wave.  The main loop is
+// one asm statement whose instruction stream -- every MFMA, LDS read, LDS-DMA piece, counted wait and barrier assigned to
+// its place -- is generated by tools/gen_gemm_w4.py (csrc/gemm_w4_asm.h; the schedule is documented there).  LDS image,
+// swizzle and tile walk are the 8-phase kernel's (units of 128 rows x 64 k, 2 stages x 4 units = 128 KiB).
+// Whole tiles only (M, N % 256 == 0, K % 64 == 0): the LDS-DMA addresses are buffer offsets (one per-lane voffset per
+// operand, a scalar offset per piece), rows are not clamped.
+// ==========================================================================================
+#include "gemm_w4_asm.h"
+
+#ifdef O2_W4_STAMP
+__device__ unsigned int o2_dbg_w4[64 * 4 * 16];   // diagnostic build only: per-wave cycle sums of the loop's segments
+extern "C" int orbit2_debug_read_w4(unsigned int* host_dst, int n) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(o2_dbg_w4), sizeof(unsigned) * (size_t)n);
+}
+#endif
+// Epilogue of the 4-wave kernel: the accumulators go through LDS (free once the main loop is over) as an fp32 image of
+// 128 tile rows x 256 columns (two passes: accumulator rows i = 0..3, then 4..7 of every wave), written straight from the
+// accumulator registers (ds_write_b128 a[..], 16-byte chunk c of image row r stored at c ^ (r & 7): conflict-free writes and
+// reads), and leave it row by row: a lane owns 8 consecutive n of a row, 32 lanes one 512-byte row segment, so every
+// epilogue load and store is a whole-line dwordx4 -- and the epilogue code (every runtime option of Epi) exists ONCE, in
+// a loop, instead of once per accumulator block (the unrolled per-block form of the 8-wave kernel is 100+ KB of code).
+__device__ __forceinline__ void w4_epilogue_rows(const Epi& epi, const char* smem, int m0, int n0, int hh, int tid) {
+  const int q = tid & 31;
+  const int n = n0 + 8 * q;
+  float bias8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bias8[k] = 0.f;
+  if (epi.bias && !epi.out_fp32) {
+    u32x4 b = {0u, 0u, 0u, 0u};
+    if (n < epi.N) b = *reinterpret_cast<const u32x4*>(epi.bias + n);
+    unpack8(b, bias8);
+  }
+  // lean path (bias / column scale only; whole tiles by construction of this kernel): per 8 values two LDS reads, the adds
+  // and multiplies of epi8_finish in its order (bit-identical), four conversions and one 16-byte store
+  const bool lean = !epi.out_fp32 && !epi.save_pre && epi.act == 0 && !epi.residual && epi.thr == 0 && !epi.dgelu_pre &&
+                    !epi.rowscale && epi.beta == 0.f;
+  if (lean) {
+    const float mul = n < epi.colscale_n ? epi.colscale : 1.0f;
+    const int r8 = tid >> 5;
+    bf16_t* cp = reinterpret_cast<bf16_t*>(epi.C) + (size_t)(m0 + hh * 64 + r8) * epi.ldc + n;
+    const size_t step8 = (size_t)8 * epi.ldc;
+    const char* lp = smem + r8 * 1024;
+    const uint32_t c0 = (uint32_t)(((2 * q) ^ r8) << 4), c1 = (uint32_t)(((2 * q + 1) ^ r8) << 4);   // (it*8 + r8) & 7 == r8
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(lp + it * 8192 + c0);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(lp + it * 8192 + c1);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (v[k] + bias8[k]) * mul;
+      *reinterpret_cast<u32x4*>(cp + (size_t)(it + (it >= 8 ? 8 : 0)) * step8) = pack8(v);
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    Pre8 pq[4];
+    f32x4 lo[4], hi[4];
+    int mm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lr = (it * 4 + k) * 8 + (tid >> 5);                  // image row 0..127
+      mm[k] = m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
+      if (!epi.out_fp32) epi8_load(epi, mm[k], n, pq[k]);
+      const char* row = smem + lr * 1024;
+      const int sw = lr & 7;
+      lo[k] = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4));
+      hi[k] = *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ sw) << 4));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (epi.out_fp32) {
+        epilogue4(epi, mm[k], n, lo[k]);
+        epilogue4(epi, mm[k], n + 4, hi[k]);
+      } else {
+        float v[8] = {lo[k][0], lo[k][1], lo[k][2], lo[k][3], hi[k][0], hi[k][1], hi[k][2], hi[k][3]};
+        epi8_finish(epi, mm[k], n, v, bias8, pq[k]);
+      }
+    }
+  }
+}
+
+// FORM: 0 = NT (A, B K-contiguous), 1 = NN (B K-strided: the stored weight in dX = dY.W), 2 = TN (both K-strided: dW = dY^T.X),
+// 3 = TT.  STAMP (diagnostic build only): per-segment cycle sums of the loop into o2_dbg_w4.
+template <int FORM, bool STAMP>
+__device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
+                                              int K, int lda, int ldb, int tiles_m, int tiles_n, const Epi& epi, int id,
+                                              char* smem) {
+  constexpr bool A_KC = (FORM == 0 || FORM == 1), B_KC = (FORM == 0 || FORM == 3);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int GROUP = 4;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsz;
+  const int tn = (id % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+#ifdef O2_W4_STAMP
+  const unsigned ts0 = (unsigned)__builtin_amdgcn_s_memtime();
+  unsigned ts[8];
+#define O2_TS(k) ts[k] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define O2_TS(k)
+#endif
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int u = lane & 15, cg = lane >> 4, sw = lane & 7;
+  // fragment read bases (stage 0) and their stage flips t = 2 base + stage size (base <- t - base)
+  uint32_t ra0, ra1, rb0, rb1;
+  const uint32_t ua = lds0 + wm * O2_W4_UNIT, ub = lds0 + (2 + wn) * O2_W4_UNIT;
+  const uint32_t kcoff0 = (uint32_t)(u * 128 + ((cg ^ sw) << 4)), kcoff1 = (uint32_t)(u * 128 + (((4 + cg) ^ sw) << 4));
+  const uint32_t ksoff = (uint32_t)((4 * (cg & 1) + (u >> 2)) * 1056 + 2 * (cg >> 1) * 256 + 8 * (lane & 3));
+  if (A_KC) { ra0 = ua + kcoff0; ra1 = ua + kcoff1; } else { ra0 = ua + ksoff; ra1 = ra0; }
+  if (B_KC) { rb0 = ub + kcoff0; rb1 = ub + kcoff1; } else { rb0 = ub + ksoff; rb1 = rb0; }
+  const uint32_t ta0 = 2 * ra0 + 4 * O2_W4_UNIT, ta1 = 2 * ra1 + 4 * O2_W4_UNIT, tb0 = 2 * rb0 + 4 * O2_W4_UNIT,
+                 tb1 = 2 * rb1 + 4 * O2_W4_UNIT;
+  // LDS-DMA sources: one per-lane byte offset per operand, a scalar offset per piece (p0 + t ps + h ph), K advance per K-tile
+  uint32_t voa, vob, pa0, psa, pha, pb0, psb, phb, ka, kb;
+  const int pr = lane >> 3, chunk = (lane & 7) ^ (pr & 7);                       // K-contiguous: piece row, swizzled 16-byte chunk
+  const int rr = lane >> 4, cp = lane & 15;                                      // K-strided: k-row within the piece, 16-byte chunk
+  const int sk0 = 32 * (wave >> 1) + 8 * (wave & 1);                             // K-strided: first k-row of this wave's pieces
+  if (A_KC) { voa = (uint32_t)(pr * lda + chunk * 8) * 2u; pa0 = (uint32_t)(wave * 32 * lda) * 2u; psa = (uint32_t)(8 * lda) * 2u; pha = (uint32_t)(128 * lda) * 2u; ka = 128u; }
+  else { voa = (uint32_t)((16 * (rr >> 1) + 4 * (rr & 1)) * lda + cp * 8) * 2u; pa0 = (uint32_t)(sk0 * lda) * 2u; psa = (uint32_t)lda * 2u; pha = 256u; ka = (uint32_t)(64 * lda) * 2u; }
+  if (B_KC) { vob = (uint32_t)(pr * ldb + chunk * 8) * 2u; pb0 = (uint32_t)(wave * 32 * ldb) * 2u; psb = (uint32_t)(8 * ldb) * 2u; phb = (uint32_t)(128 * ldb) * 2u; kb = 128u; }
+  else { vob = (uint32_t)((16 * (rr >> 1) + 4 * (rr & 1)) * ldb + cp * 8) * 2u; pb0 = (uint32_t)(sk0 * ldb) * 2u; psb = (uint32_t)ldb * 2u; phb = 256u; kb = (uint32_t)(64 * ldb) * 2u; }
+  const auto srda = __builtin_amdgcn_make_buffer_rsrc((void*)(A_KC ? A + (size_t)m0 * lda : A + m0), 0, 0x7fffffff, 0x00020000);
+  const auto srdb = __builtin_amdgcn_make_buffer_rsrc((void*)(B_KC ? B + (size_t)n0 * ldb : B + n0), 0, 0x7fffffff, 0x00020000);
+  const uint32_t ldswa = lds0 + wave * 4 * (A_KC ? 1024 : 1056);
+  const uint32_t ldswb = lds0 + 2 * O2_W4_UNIT + wave * 4 * (B_KC ? 1024 : 1056);
+  const uint32_t nk = (uint32_t)(K / BK3);
+#define O2_W4_OPERANDS                                                                                                   \
+               [srda] "s"(srda), [srdb] "s"(srdb), [pa0] "s"(pa0), [psa] "s"(psa), [pha] "s"(pha), [pb0] "s"(pb0),       \
+               [psb] "s"(psb), [phb] "s"(phb), [ldswa] "s"(ldswa), [ldswb] "s"(ldswb), [nk] "s"(nk), [ka] "s"(ka),       \
+               [kb] "s"(kb), [ta0] "v"(ta0), [ta1] "v"(ta1), [tb0] "v"(tb0), [tb1] "v"(tb1)
+  if constexpr (!STAMP) {
+#define O2_W4_RUN(STR)                                                                                                   \
+  asm volatile(STR                                                                                                       \
+               : [voa] "+v"(voa), [vob] "+v"(vob), [ra0] "+v"(ra0), [ra1] "+v"(ra1), [rb0] "+v"(rb0), [rb1] "+v"(rb1)   \
+               : O2_W4_OPERANDS                                                                                          \
+               : O2_W4_CLOBBERS)
+    if constexpr (FORM == 0) O2_W4_RUN(O2_W4_ASM_NT);
+    if constexpr (FORM == 1) O2_W4_RUN(O2_W4_ASM_NN);
+    if constexpr (FORM == 2) O2_W4_RUN(O2_W4_ASM_TN);
+    if constexpr (FORM == 3) O2_W4_RUN(O2_W4_ASM_TT);
+#undef O2_W4_RUN
+  }
+#ifdef O2_W4_STAMP
+  if constexpr (STAMP) {
+    unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    O2_TS(0);
+#define O2_W4_RUNS(STR)                                                                                                  \
+  asm volatile(STR                                                                                                       \
+               : [voa] "+v"(voa), [vob] "+v"(vob), [ra0] "+v"(ra0), [ra1] "+v"(ra1), [rb0] "+v"(rb0), [rb1] "+v"(rb1),  \
+                 [t0] "+s"(t0), [t1] "+s"(t1), [t2] "+s"(t2), [t3] "+s"(t3), [t4] "+s"(t4)                               \
+               : O2_W4_OPERANDS                                                                                          \
+               : O2_W4_CLOBBERS)
+    if constexpr (FORM == 0) O2_W4_RUNS(O2_W4_ASM_NT_STAMP);
+    if constexpr (FORM == 1) O2_W4_RUNS(O2_W4_ASM_NN_STAMP);
+    if constexpr (FORM == 2) O2_W4_RUNS(O2_W4_ASM_TN_STAMP);
+    if constexpr (FORM == 3) O2_W4_RUNS(O2_W4_ASM_TT_STAMP);
+#undef O2_W4_RUNS
+    O2_TS(1);
+    if (blockIdx.x < 64 && lane == 0) {
+      unsigned* d = o2_dbg_w4 + (blockIdx.x * 4 + wave) * 16;
+      d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = t4; d[5] = nk;
+    }
+  }
+#endif
+#undef O2_W4_OPERANDS
+  // epilogue: two passes through the LDS image (see w4_epilogue_rows)
+  const uint32_t crow = lds0 + (uint32_t)(wm * 64 + u) * 1024u;
+  const uint32_t be = crow + (uint32_t)(((wn * 32 + cg) ^ sw) << 4), bo = crow + (uint32_t)(((wn * 32 + 4 + cg) ^ sw) << 4);
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    __syncthreads();                                 // pass 0: every wave's last LDS-DMA pieces have landed, nobody reads the stages
+    if (hh == 0) asm volatile(O2_W4_CSTAGE0 : : [be] "v"(be), [bo] "v"(bo) : "memory");
+    else asm volatile(O2_W4_CSTAGE1 : : [be] "v"(be), [bo] "v"(bo) : "memory");
+    __syncthreads();
+    if (hh == 0) { O2_TS(2); } else { O2_TS(4); }
+    w4_epilogue_rows(epi, smem, m0, n0, hh, tid);
+    if (hh == 0) { O2_TS(3); } else { O2_TS(5); }
+  }
+#ifdef O2_W4_STAMP
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    O2_TS(6);
+    if (blockIdx.x < 64 && lane == 0) {
+      unsigned* d = o2_dbg_w4 + (blockIdx.x * 4 + wave) * 16;
+      for (int k = 0; k < 7; ++k) d[8 + k] = ts[k] - ts0;
+    }
+  }
+#endif
+#undef O2_TS
+}
+
+template <int FORM, bool STAMP>
+__global__ __launch_bounds__(256, 1) void gemm256w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                          int M, int N, int K, int lda, int ldb, int tiles_m,
+                                                          int tiles_n, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
+  gemm256w_tile<FORM, STAMP>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256, 1) void gemm256w_grouped_kernel(GArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
+  const int id = xcd_tile_id();
+  int pi = 0;
+  while (pi + 1 < g.n && id >= g.p[pi].tile_end) ++pi;
+  const int first = pi ? g.p[pi - 1].tile_end : 0;
+  const GProb& P = g.p[pi];
+  const Epi epi = P.epi;
+  gemm256w_tile<FORM, false>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // small fp32 GEMM (table algebra; sizes ~ [115 x D] x [D x D]): 64x64 tile, 16x16 threads, 4x4 micro-tile
 // ------------------------------------------------------------------------------------------
@@ -863,13 +1085,42 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
   if (tile == 257 || tile == 258) tile = 256;       // hints of the round-2 A/B tools: the same kernel
-  if (tile != 128 && tile != 256) {
+  if (tile != 128 && tile != 256 && tile != 260 && tile != 261) {
     // measured on MI355X (tools/gemm_p8_ab.py, tools/gemm_t8_ab.py; profiles/r02_gemm_*): the 8-phase 256-tile kernel wins
     // in every operand form whenever its tiles fill the chip; the 128^2 kernel (2 workgroups/CU, ragged K) takes small
     // or ragged problems
     const long rounds = (t256 + 255) / 256;
     const double util = (double)t256 / (double)(rounds * 256);
     tile = (a->K % BK3 == 0 && a->K >= 2 * BK3 && a->M >= 256 && a->N >= 256 && t256 >= 192 && util >= 0.70) ? 256 : 128;
+  }
+  if (tile == 260 || tile == 261) {                   // 4-wave kernel: whole tiles (261: its stamped diagnostic form)
+    if (a->M % 256 || a->N % 256 || a->K % BK3) return O2_ERR_ARG;
+    const int tiles_m = a->M / BM2, tiles_n = a->N / BN2;
+    const dim3 grid(tiles_m * tiles_n), block(256);
+    const int form = a->a_kc ? (a->b_kc ? 0 : 1) : (a->b_kc ? 3 : 2);
+#define O2_W4_LAUNCH(F, S) hipLaunchKernelGGL((gemm256w_kernel<F, S>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb, tiles_m, tiles_n, e)
+    if (tile == 260) {
+      switch (form) {
+        case 0: O2_W4_LAUNCH(0, false); break;
+        case 1: O2_W4_LAUNCH(1, false); break;
+        case 2: O2_W4_LAUNCH(2, false); break;
+        default: O2_W4_LAUNCH(3, false); break;
+      }
+    } else {
+#ifdef O2_W4_STAMP
+      switch (form) {
+        case 0: O2_W4_LAUNCH(0, true); break;
+        case 1: O2_W4_LAUNCH(1, true); break;
+        case 2: O2_W4_LAUNCH(2, true); break;
+        default: O2_W4_LAUNCH(3, true); break;
+      }
+#else
+      return O2_ERR_UNSUPPORTED;
+#endif
+    }
+#undef O2_W4_LAUNCH
+    O2_CHECK_LAUNCH();
+    return O2_OK;
   }
   if (tile == 256) {
     const int tiles_m = (a->M + BM2 - 1) / BM2, tiles_n = (a->N + BN2 - 1) / BN2;
