@@ -49,7 +49,8 @@ typedef struct {
   int ldr, res_mod, res_first;
   int out_fp32;            /* 0: C is bf16, 1: C is fp32 */
   float beta;              /* C = beta*C + result (gradient accumulation) */
-  int tile_hint;           /* 0 = auto, 128 or 256 = force that kernel (tests / tuning; 256 needs K % 64 == 0) */
+  int tile_hint;           /* 0 = auto; tests / tuning: 128 = 128-tile kernel, 256 = 8-wave 8-phase kernel (K % 64 == 0),
+                              260 = 4-wave kernel (M, N % 256 == 0, K % 64 == 0) */
   int colscale_n;          /* columns n < colscale_n (a multiple of 8; 0 = none) are multiplied by colscale in fp32 right after */
   float colscale;          /*   the bias: the qkv Linear stores q * log2(e)/sqrt(d) (attention.py:50,54: q * scale), rounded ONCE */
 } orbit2_gemm_args;

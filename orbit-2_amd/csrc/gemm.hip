@@ -719,31 +719,48 @@ __device__ __forceinline__ void w4_epilogue_rows(const Epi& epi, const char* sme
     }
     return;
   }
+  if (epi.out_fp32) {
 #pragma unroll 1
-  for (int it = 0; it < 4; ++it) {
-    Pre8 pq[4];
-    f32x4 lo[4], hi[4];
-    int mm[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int lr = (it * 4 + k) * 8 + (tid >> 5);                  // image row 0..127
-      mm[k] = m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
-      if (!epi.out_fp32) epi8_load(epi, mm[k], n, pq[k]);
+    for (int it = 0; it < 16; ++it) {
+      const int lr = it * 8 + (tid >> 5);                            // image row 0..127
+      const int m = m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
       const char* row = smem + lr * 1024;
       const int sw = lr & 7;
-      lo[k] = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4));
-      hi[k] = *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ sw) << 4));
+      epilogue4(epi, m, n, *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4)));
+      epilogue4(epi, m, n + 4, *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ sw) << 4)));
     }
+    return;
+  }
+  // generic bf16 path: four rows per step, the loads of the next step (residual / pre-activation / old C) in flight while
+  // this step is finished -- with one wave per SIMD nobody else hides their latency
+  auto row_m = [&](int it, int k) {
+    const int lr = (it * 4 + k) * 8 + (tid >> 5);
+    return m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
+  };
+  auto load4 = [&](int it, Pre8 (&pq)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) epi8_load(epi, row_m(it, k), n, pq[k]);
+  };
+  auto finish4 = [&](int it, const Pre8 (&pq)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (epi.out_fp32) {
-        epilogue4(epi, mm[k], n, lo[k]);
-        epilogue4(epi, mm[k], n + 4, hi[k]);
-      } else {
-        float v[8] = {lo[k][0], lo[k][1], lo[k][2], lo[k][3], hi[k][0], hi[k][1], hi[k][2], hi[k][3]};
-        epi8_finish(epi, mm[k], n, v, bias8, pq[k]);
-      }
+      const int lr = (it * 4 + k) * 8 + (tid >> 5);
+      const char* row = smem + lr * 1024;
+      const int sw = lr & 7;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ sw) << 4));
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      epi8_finish(epi, row_m(it, k), n, v, bias8, pq[k]);
     }
+  };
+  Pre8 qa[4], qb[4];
+  load4(0, qa);
+#pragma unroll 1
+  for (int it2 = 0; it2 < 2; ++it2) {
+    load4(2 * it2 + 1, qb);
+    finish4(2 * it2, qa);
+    if (it2 == 0) load4(2, qa);
+    finish4(2 * it2 + 1, qb);
   }
 }
 
@@ -1056,6 +1073,17 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
   }
   hipStream_t s = (hipStream_t)stream;
   if (big) {
+    bool whole = args[0].tile_hint != 256;           // the 4-wave kernel takes whole tiles only (hint 256 forces the 8-phase kernel)
+    for (int i = 0; i < n; ++i) whole = whole && args[i].M % 256 == 0 && args[i].N % 256 == 0;
+    if (whole) {
+      dim3 grid(total), block(256);
+      if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<0>), grid, block, 0, s, g);
+      else if (args[0].a_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<1>), grid, block, 0, s, g);
+      else if (args[0].b_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<3>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm256w_grouped_kernel<2>), grid, block, 0, s, g);
+      O2_CHECK_LAUNCH();
+      return O2_OK;
+    }
     dim3 grid(total), block(512);
     if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm256t_grouped_kernel<true, true>), grid, block, 0, s, g);
     else if (args[0].a_kc) hipLaunchKernelGGL((gemm256t_grouped_kernel<true, false>), grid, block, 0, s, g);
@@ -1086,12 +1114,20 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   int tile = a->tile_hint;
   if (tile == 257 || tile == 258) tile = 256;       // hints of the round-2 A/B tools: the same kernel
   if (tile != 128 && tile != 256 && tile != 260 && tile != 261) {
-    // measured on MI355X (tools/gemm_p8_ab.py, tools/gemm_t8_ab.py; profiles/r02_gemm_*): the 8-phase 256-tile kernel wins
-    // in every operand form whenever its tiles fill the chip; the 128^2 kernel (2 workgroups/CU, ragged K) takes small
-    // or ragged problems
+    // measured on MI355X (tools/gemm_p8_ab.py, tools/gemm_t8_ab.py, tools/gemm_w4_ab.py; profiles/r02_gemm_*, r03_gemm_w4_*): a
+    // 256-tile kernel wins in every operand form whenever its tiles fill the chip -- the 4-wave kernel on whole tiles
+    // (+7 ... +16 % over the 8-phase kernel), the 8-phase kernel on ragged M / N; the 128^2 kernel (2 workgroups/CU, ragged K)
+    // takes small or ragged problems
     const long rounds = (t256 + 255) / 256;
     const double util = (double)t256 / (double)(rounds * 256);
     tile = (a->K % BK3 == 0 && a->K >= 2 * BK3 && a->M >= 256 && a->N >= 256 && t256 >= 192 && util >= 0.70) ? 256 : 128;
+    // the 4-wave kernel: whole tiles, and an epilogue that is not vector-ALU heavy -- one wave per SIMD issues vector
+    // instructions at half the rate two waves reach, so GELU / GELU' / dropout epilogues (~35 instructions per value) cost it
+    // more than its main loop gains (profiles/r03_gemm_w4_epilogues.txt); K-contiguous operands whose rows are BOTH a
+    // multiple of 8 KiB apart (fc2-shaped: every row's k-offset on the same memory channel) also stay on the 8-phase kernel
+    const bool heavy = e.act != 0 || e.thr != 0 || e.dgelu_pre != nullptr;
+    const bool camped = a->a_kc && a->b_kc && a->K >= 8192 && a->lda % 4096 == 0 && a->ldb % 4096 == 0;
+    if (tile == 256 && a->M % 256 == 0 && a->N % 256 == 0 && !heavy && !camped) tile = 260;
   }
   if (tile == 260 || tile == 261) {                   // 4-wave kernel: whole tiles (261: its stamped diagnostic form)
     if (a->M % 256 || a->N % 256 || a->K % BK3) return O2_ERR_ARG;

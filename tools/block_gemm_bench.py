@@ -37,10 +37,19 @@ cases = [
     ("fc1 shape plain", lambda kw: _hip.gemm(x, w1, oH, M, hid, D, D, D, hid, **kw), hid, D),
     ("qkv shape plain", lambda kw: _hip.gemm(x, wqkv, o3, M, 3 * D, D, D, D, 3 * D, **kw), 3 * D, D),
 ]
-tot = 0.0
+hints = [int(h) for h in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]     # e.g. 256,260: 8-phase against 4-wave kernel
+tot = {h: 0.0 for h in hints}
 for name, f, N, K in cases:
-    ms = t(lambda: f({}))
     fl = 2.0 * M * N * K
-    if "shape" not in name: tot += ms
-    print("%-36s N=%6d K=%6d | %7.3f ms %6.0f TF" % (name, N, K, ms, fl / ms / 1e9), flush=True)
-print("block NT total %.3f ms (x8 blocks = %.1f ms/step)" % (tot, 8 * tot))
+    ms = {h: [] for h in hints}
+    for rnd in range(3):
+        for h in hints:
+            ms[h].append(t(lambda: f({"tile": h} if h else {})))
+    line = "%-36s N=%6d K=%6d" % (name, N, K)
+    for h in hints:
+        m = sorted(ms[h])[1]
+        if "shape" not in name: tot[h] += m
+        line += " | [%d] %7.3f ms %6.0f TF" % (h, m, fl / m / 1e9)
+    print(line, flush=True)
+for h in hints:
+    print("[%d] block NT total %.3f ms (x8 blocks = %.1f ms/step)" % (h, tot[h], 8 * tot[h]))
