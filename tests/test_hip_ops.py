@@ -63,6 +63,70 @@ def test_gemm_forms(hip, M, N, K, form, tile):
     assert nerr(outb, ref) < 6e-3  # one bf16 rounding of the result (2^-8 relative)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 128), (512, 768, 192), (1024, 1024, 512), (768, 256, 1088)])
+@pytest.mark.parametrize("form", ["nt", "nn", "tn", "tt"])
+def test_gemm_forms_4wave_kernel(hip, M, N, K, form):
+    """the 4-wave 256x256x64 kernel (tile hint 260; whole tiles, hand-placed main loop, csrc/gemm_w4_asm.h): every operand
+    form against the fp32 product, K-tiles 1, 2 and 3 (pipeline prologue / dead-slot loads), an odd count (17), and bit-equality
+    with the 8-phase kernel (same k order per accumulator) for fp32, bf16 and beta-accumulating outputs"""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rt(torch.randn(M, K, generator=g))
+    B = rt(torch.randn(N, K, generator=g))
+    ref = A @ B.t()
+    a_kc, b_kc = form[0] == "n", form[1] == "t"
+    Ad = bf(A if a_kc else A.t().contiguous()).cuda()
+    Bd = bf(B if b_kc else B.t().contiguous()).cuda()
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+    outs = {}
+    for tile in (260, 256):
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(Ad, Bd, out, M, N, K, lda, ldb, N, a_kc=a_kc, b_kc=b_kc, tile=tile)
+        outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(Ad, Bd, outb, M, N, K, lda, ldb, N, a_kc=a_kc, b_kc=b_kc, tile=tile)
+        acc = torch.full((M, N), 0.5, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(Ad, Bd, acc, M, N, K, lda, ldb, N, a_kc=a_kc, b_kc=b_kc, beta=1.0, tile=tile)
+        outs[tile] = (out, outb, acc)
+    torch.cuda.synchronize()
+    assert nerr(outs[260][0], ref) < 2e-5
+    assert nerr(outs[260][1], ref) < 6e-3
+    assert nerr(outs[260][2], ref + 0.5) < 6e-3
+    for x, y in zip(outs[260], outs[256]):
+        assert torch.equal(x, y)
+
+
+def test_gemm_4wave_kernel_takes_whole_tiles_only(hip):
+    A, B = bf(torch.randn(264, 128)).cuda(), bf(torch.randn(256, 128)).cuda()
+    out = torch.empty(264, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(Exception):
+        hip.gemm(A, B, out, 264, 256, 128, 128, 128, 256, tile=260)
+    hip.gemm(A, B, out, 264, 256, 128, 128, 128, 256)          # auto: the 8-phase / 128-tile kernels take it
+    assert nerr(out, A.float().cpu() @ B.float().cpu().t()) < 6e-3
+
+
+def test_gemm_grouped_4wave_matches_single_launches(hip):
+    """a grouped launch of whole-tile problems runs on the 4-wave kernel: equal, bit for bit, to the same problems launched
+    one by one on it (weight-gradient form with a beta-accumulating member, and the forward form)"""
+    g = torch.Generator().manual_seed(78)
+    for a_kc, b_kc in ((False, False), (True, True)):
+        probs, refs = [], []
+        for i, (M, N, K) in enumerate([(256, 512, 192), (768, 256, 128), (256, 256, 320), (512, 1024, 64)]):
+            A = bf(torch.randn((M, K) if a_kc else (K, M), generator=g)).cuda()
+            B = bf(torch.randn((N, K) if b_kc else (K, N), generator=g)).cuda()
+            beta = 1.0 if i == 1 else 0.0
+            c0 = bf(torch.randn(M, N, generator=g)).cuda()
+            single = c0.clone()
+            hip.gemm(A, B, single, M, N, K, A.shape[1], B.shape[1], N, a_kc=a_kc, b_kc=b_kc, beta=beta, tile=260)
+            out = c0.clone()
+            probs.append((A, B, out, M, N, K, A.shape[1], B.shape[1], N, dict(a_kc=a_kc, b_kc=b_kc, beta=beta, tile=258)))
+            refs.append(single)
+            ref32 = (A.float().cpu() if a_kc else A.float().cpu().t()) @ (B.float().cpu().t() if b_kc else B.float().cpu())
+            assert nerr(single, ref32 + beta * c0.float().cpu()) < 8e-3
+        hip.gemm_grouped(probs)
+        torch.cuda.synchronize()
+        for pr, ref in zip(probs, refs):
+            assert torch.equal(pr[2], ref)
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M", [12, 100, 301])
 def test_gemm_any_row_count_when_a_is_k_contiguous(hip, M, tile):
@@ -120,9 +184,9 @@ def test_gemm_grouped_matches_single_launches(hip, form):
         assert torch.equal(pr[2], ref)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
-def test_gemm_epilogue_full(hip, tile):
-    M, N, K, L = 256, 192, 128, 64
+@pytest.mark.parametrize("tile,M,N", [(128, 256, 192), (256, 256, 192), (260, 512, 256)])
+def test_gemm_epilogue_full(hip, tile, M, N):
+    K, L = 128, 64
     g = torch.Generator().manual_seed(5)
     A, W = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.2)
     bias, res = rt(torch.randn(N, generator=g)), rt(torch.randn(L, N, generator=g))
@@ -160,11 +224,11 @@ def test_gemm_epilogue_full(hip, tile):
     assert nerr(dgb, (A @ W.t()) * mask * sc * prq.grad) < 6e-3
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 260])
 def test_gemm_column_scale(hip, tile):
     """colscale epilogue (the qkv Linear's q third times log2(e)/sqrt(d)): columns n < colscale_n are multiplied in fp32
     right after the bias -- one rounding to bf16 -- the rest are untouched bit for bit; fp32 and bf16 outputs"""
-    M, N, K, n0, c = 256, 384, 128, 128, 0.12752041
+    M, N, K, n0, c = 256, 512, 128, 128, 0.12752041
     g = torch.Generator().manual_seed(6)
     A, W, bias = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.2), rt(torch.randn(N, generator=g))
     ref = A @ W.t() + bias
