@@ -86,6 +86,13 @@ def _dev(t: torch.Tensor, dtype, name: str):
 BF, F32 = torch.bfloat16, torch.float32
 
 
+def _dev_rows(t: torch.Tensor, dtype, name: str):
+    """a GEMM operand / epilogue tensor handed over with an explicit leading dimension: rows contiguous, any row pitch"""
+    if t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == dtype:
+        return t
+    return _dev(t, dtype, name)
+
+
 class KernelTimer:
     """Optional live timing of individual launches with HIP events recorded on the launch stream
     (bench.py uses it for the roofline of the dominant kernel).  Off unless `_hip.timer` is set."""
@@ -116,7 +123,7 @@ def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=
                dgelu_pre=None, drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0,
                res_first=False, beta=0.0, tile=0, colscale=None):
     for t, nm in ((A, "A"), (B, "B")):
-        _dev(t, BF, nm)
+        _dev_rows(t, BF, nm)
     if out.dtype not in (BF, F32) or not out.is_cuda:
         raise HipBackendError("gemm out must be a bf16/fp32 GPU tensor")
     a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -124,8 +131,8 @@ def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=
     a.a_kc, a.b_kc = int(a_kc), int(b_kc)
     a.bias = None if bias is None else _dev(bias, BF, "bias").data_ptr()
     a.act = act
-    a.save_pre = None if save_pre is None else _dev(save_pre, BF, "save_pre").data_ptr()
-    a.dgelu_pre = None if dgelu_pre is None else _dev(dgelu_pre, BF, "dgelu_pre").data_ptr()
+    a.save_pre = None if save_pre is None else _dev_rows(save_pre, BF, "save_pre").data_ptr()      # row pitch = ldc
+    a.dgelu_pre = None if dgelu_pre is None else _dev_rows(dgelu_pre, BF, "dgelu_pre").data_ptr()  # row pitch = ldc
     a.drop_p, a.seed = float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     a.rowscale = None if rowscale is None else _dev(rowscale, F32, "rowscale").data_ptr()
     a.rows_per_scale = rows_per_scale

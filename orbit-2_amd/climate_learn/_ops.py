@@ -149,28 +149,48 @@ def _needs(ctx, i):
     return ctx.needs_input_grad[i]
 
 
-def _linear_fwd(x2d, W, b, M, N, K, **kw):
-    out = torch.empty(M, N, dtype=BF, device=x2d.device)
-    return _hip.gemm(x2d, cw(W), out, M, N, K, K, K, N, bias=None if b is None else cw(b), **kw)
+def _ld_pad(n: int) -> int:
+    """row pitch (elements) of a [rows, n] bf16 activation that only GEMMs and column sums touch: rows a multiple of 8 KiB apart
+    put the same k-offset of EVERY row on the same memory channel (the MLP hidden tensors of interm_1b: 24 KiB rows) and the
+    LDS-DMA pieces of a GEMM, 4-8 rows each, queue on it: -13 % on the weight-gradient GEMMs that read them K-strided, -20 % on
+    a K-contiguous 4-wave GEMM (profiles/r03_gemm_ld_pad.txt).  128 bytes of padding per row spread them."""
+    return n + 64 if (2 * n) % 8192 == 0 else n
 
 
-def _dx(dy2d, W, M, N, K, **kw):
+def _ld(t, n):
+    """leading dimension of a row-major [rows, n] operand (a padded _rows view, or a contiguous tensor of any rank)"""
+    return t.stride(0) if t.dim() == 2 else n
+
+
+def _rows(M, N, device):
+    """[M, N] bf16 with the row pitch of _ld_pad (a view when padded: every consumer takes the leading dimension from stride(0))"""
+    ld = _ld_pad(N)
+    buf = torch.empty(M, ld, dtype=BF, device=device)
+    return buf if ld == N else buf[:, :N]
+
+
+def _linear_fwd(x2d, W, b, M, N, K, pad=False, **kw):
+    out = _rows(M, N, x2d.device) if pad else torch.empty(M, N, dtype=BF, device=x2d.device)
+    return _hip.gemm(x2d, cw(W), out, M, N, K, _ld(x2d, K), K, out.stride(0), bias=None if b is None else cw(b), **kw)
+
+
+def _dx(dy2d, W, M, N, K, pad=False, **kw):
     """dx[M,K] = dy[M,N] . W[N,K] on the weight AS STORED: W is the K-strided operand, read through the
     hardware-transposing LDS path of the 8-phase kernel (as fast as the K-contiguous form on a transposed copy --
     profiles/r02_gemm_t8_ab.txt -- so the per-step transposed weight copies of round 1 are gone)."""
-    out = torch.empty(M, K, dtype=BF, device=dy2d.device)
-    return _hip.gemm(dy2d, cw(W), out, M, K, N, N, K, K, a_kc=True, b_kc=False, **kw)
+    out = _rows(M, K, dy2d.device) if pad else torch.empty(M, K, dtype=BF, device=dy2d.device)
+    return _hip.gemm(dy2d, cw(W), out, M, K, N, _ld(dy2d, N), K, out.stride(0), a_kc=True, b_kc=False, **kw)
 
 
 def _dw(dy2d, x2d, W, b, M, N, K):
     """dW[N,K] = dy^T . x ; db[N] = colsum(dy).  Returns what backward must return for (W, b)."""
     sw = _GradSink(W)
-    _hip.gemm(dy2d, x2d, sw.buf, N, K, M, N, K, K, a_kc=False, b_kc=False, beta=sw.beta)
+    _hip.gemm(dy2d, x2d, sw.buf, N, K, M, _ld(dy2d, N), _ld(x2d, K), K, a_kc=False, b_kc=False, beta=sw.beta)
     gw = sw.done()
     gb = None
     if b is not None:
         sb = _GradSink(b)
-        _hip.colsum(dy2d, M, N, N, sb.buf, beta=sb.beta)
+        _hip.colsum(dy2d, M, N, _ld(dy2d, N), sb.buf, beta=sb.beta)
         gb = sb.done()
     return gw, gb
 
@@ -186,13 +206,14 @@ class _DwBatch:
     def add(self, dy2d, x2d, W, b, M, N, K):
         """queues dW[N,K] = dy^T . x; returns (index of the weight result, bias result)"""
         sw = _GradSink(W)
-        self.problems.append((dy2d, x2d, sw.buf, N, K, M, N, K, K, dict(a_kc=False, b_kc=False, beta=sw.beta)))
+        self.problems.append((dy2d, x2d, sw.buf, N, K, M, _ld(dy2d, N), _ld(x2d, K), K,
+                              dict(a_kc=False, b_kc=False, beta=sw.beta)))
         self.sinks.append(sw)
         self.keep.append((dy2d, x2d))
         gb = None
         if b is not None:
             sb = _GradSink(b)
-            _hip.colsum(dy2d, M, N, N, sb.buf, beta=sb.beta)
+            _hip.colsum(dy2d, M, N, _ld(dy2d, N), sb.buf, beta=sb.beta)
             gb = sb.done()
         return len(self.sinks) - 1, gb
 
@@ -287,8 +308,8 @@ class BlockFn(torch.autograd.Function):
             _tp.all_reduce_sum(part, grp)
             x1 = _hip.post_reduce(part, M, D, residual=x2d, rowscale=dp1, rows_per_scale=L)
         h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b))
-        pre = torch.empty(M, hid, dtype=BF, device=x2d.device)
-        hm = _linear_fwd(h2, w1, b1, M, hid, D, act=1, save_pre=pre, drop_p=p_mlp, seed=s1)
+        pre = _rows(M, hid, x2d.device)           # the hidden tensors (pre, hm, and dpre in backward) carry _ld_pad's row pitch
+        hm = _linear_fwd(h2, w1, b1, M, hid, D, pad=True, act=1, save_pre=pre, drop_p=p_mlp, seed=s1)
         if grp is None:
             x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
                              residual=x1, ldr=D)
@@ -319,7 +340,7 @@ class BlockFn(torch.autograd.Function):
         dym2, gb2, done2 = _drop_bwd_bias(dx2, M, D, p_mlp, s2, dp2, L, b2)      # fc2's bias gradient rides along
         i2, gb2_ = dws.add(dym2, hm, w2, None if done2 else b2, M, D, hid)
         gb2 = gb2 if done2 else gb2_
-        dpre = _dx(dym2, w2, M, D, hid, drop_p=p_mlp, seed=s1, dgelu_pre=pre)
+        dpre = _dx(dym2, w2, M, D, hid, pad=True, drop_p=p_mlp, seed=s1, dgelu_pre=pre)
         del hm, pre, dym2
         i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D)
         dh2 = _dx(dpre, w1, M, hid, D)

@@ -274,9 +274,15 @@ def show(name):
 
 if __name__ == "__main__":
     import sys
+    # tuning: --cfg "lstride=5,bar2=88" overrides BASE, --out PATH writes the header elsewhere (tools/mkvar_w4.sh)
+    if "--cfg" in sys.argv:
+        for kv in sys.argv[sys.argv.index("--cfg") + 1].split(","):
+            k, v = kv.split("=")
+            BASE[k] = int(v)
     if len(sys.argv) > 2 and sys.argv[1] == "show":
         show(sys.argv[2])
     else:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        emit(os.path.join(root, "orbit-2_amd", "csrc", "gemm_w4_asm.h"))
-        print("wrote gemm_w4_asm.h:", ", ".join(FORMS))
+        out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(root, "orbit-2_amd", "csrc", "gemm_w4_asm.h")
+        emit(out)
+        print("wrote %s:" % out, ", ".join(FORMS), BASE)
