@@ -484,11 +484,12 @@ def main():
         split = None       # Infinity-Cache hits vs HBM reads inside that counter traffic (mean L2-miss latency of the step's kernels)
         try:
             mj = json.load(open(os.path.join(ROOT, "profiles", MALL_JSON)))
-            share = {k: v["infinity_cache_hit_share_est"] for k, v in mj.items() if isinstance(v, dict) and "gemm256t" in k
+            share = {k: v["infinity_cache_hit_share_est"] for k, v in mj.items() if isinstance(v, dict) and "gemm256" in k
                      and "infinity_cache_hit_share_est" in v}
             if share and traffic is not None:
-                fam = {"gemm_8phase_single": min(v for k, v in share.items() if "grouped" not in k),
-                       "gemm_8phase_grouped_dw": min([v for k, v in share.items() if "grouped" in k] or [0.0])}
+                pick = lambda tag, grouped: [v for k, v in share.items() if tag in k and ("grouped" in k) == grouped]
+                fam = {f: min(v) for f, v in (("gemm_8phase_single", pick("gemm256t", False)), ("gemm_8phase_grouped_dw", pick("gemm256t", True)),
+                                              ("gemm_w4_single", pick("gemm256w", False)), ("gemm_w4_grouped_dw", pick("gemm256w", True))) if v}
                 num = den = 0.0
                 for f, sh in fam.items():
                     if f in tj:                      # per-family counter traffic x (1 - Infinity-Cache share of its reads)

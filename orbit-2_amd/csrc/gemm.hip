@@ -731,36 +731,32 @@ __device__ __forceinline__ void w4_epilogue_rows(const Epi& epi, const char* sme
     }
     return;
   }
-  // generic bf16 path: four rows per step, the loads of the next step (residual / pre-activation / old C) in flight while
-  // this step is finished -- with one wave per SIMD nobody else hides their latency
-  auto row_m = [&](int it, int k) {
+}
+
+// generic bf16 epilogue of the 4-wave kernel (any combination of Epi's options): four image rows per step and lane, the
+// loads (residual / pre-activation / old C) two steps ahead of their use -- the first two steps' loads are issued BEFORE the
+// accumulators are staged through LDS: with one wave per SIMD nobody else hides their latency (at one step ahead the
+// epilogue ran at the ~2 TB/s its 32 KB in flight per CU allow)
+__device__ __forceinline__ int w4_row_m(int m0, int hh, int tid, int it, int k) {
+  const int lr = (it * 4 + k) * 8 + (tid >> 5);
+  return m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
+}
+__device__ __forceinline__ void w4_generic_load(const Epi& epi, int m0, int n, int hh, int tid, int it, Pre8 (&pq)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) epi8_load(epi, w4_row_m(m0, hh, tid, it, k), n, pq[k]);
+}
+__device__ __forceinline__ void w4_generic_finish(const Epi& epi, const char* smem, int m0, int n, int hh, int tid, int it,
+                                                  const float* bias8, const Pre8 (&pq)[4]) {
+  const int q = tid & 31;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
     const int lr = (it * 4 + k) * 8 + (tid >> 5);
-    return m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
-  };
-  auto load4 = [&](int it, Pre8 (&pq)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) epi8_load(epi, row_m(it, k), n, pq[k]);
-  };
-  auto finish4 = [&](int it, const Pre8 (&pq)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int lr = (it * 4 + k) * 8 + (tid >> 5);
-      const char* row = smem + lr * 1024;
-      const int sw = lr & 7;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4));
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ sw) << 4));
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      epi8_finish(epi, row_m(it, k), n, v, bias8, pq[k]);
-    }
-  };
-  Pre8 qa[4], qb[4];
-  load4(0, qa);
-#pragma unroll 1
-  for (int it2 = 0; it2 < 2; ++it2) {
-    load4(2 * it2 + 1, qb);
-    finish4(2 * it2, qa);
-    if (it2 == 0) load4(2, qa);
-    finish4(2 * it2 + 1, qb);
+    const char* row = smem + lr * 1024;
+    const int sw = lr & 7;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4));
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ sw) << 4));
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    epi8_finish(epi, w4_row_m(m0, hh, tid, it, k), n, v, bias8, pq[k]);
   }
 }
 
@@ -855,17 +851,40 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   }
 #endif
 #undef O2_W4_OPERANDS
-  // epilogue: two passes through the LDS image (see w4_epilogue_rows)
+  // epilogue: two passes through the LDS image (see w4_epilogue_rows / w4_generic_*)
   const uint32_t crow = lds0 + (uint32_t)(wm * 64 + u) * 1024u;
   const uint32_t be = crow + (uint32_t)(((wn * 32 + cg) ^ sw) << 4), bo = crow + (uint32_t)(((wn * 32 + 4 + cg) ^ sw) << 4);
+  const bool lean = !epi.out_fp32 && !epi.save_pre && epi.act == 0 && !epi.residual && epi.thr == 0 && !epi.dgelu_pre &&
+                    !epi.rowscale && epi.beta == 0.f;
+  const bool generic = !lean && !epi.out_fp32;
+  const int ne = n0 + 8 * (tid & 31);
+  float bias8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bias8[k] = 0.f;
+  if (generic && epi.bias) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
 #pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
+    Pre8 qa[4], qb[4];
+    if (generic) {
+      w4_generic_load(epi, m0, ne, hh, tid, 0, qa);
+      w4_generic_load(epi, m0, ne, hh, tid, 1, qb);
+    }
     __syncthreads();                                 // pass 0: every wave's last LDS-DMA pieces have landed, nobody reads the stages
     if (hh == 0) asm volatile(O2_W4_CSTAGE0 : : [be] "v"(be), [bo] "v"(bo) : "memory");
     else asm volatile(O2_W4_CSTAGE1 : : [be] "v"(be), [bo] "v"(bo) : "memory");
     __syncthreads();
     if (hh == 0) { O2_TS(2); } else { O2_TS(4); }
-    w4_epilogue_rows(epi, smem, m0, n0, hh, tid);
+    if (generic) {
+#pragma unroll 1
+      for (int it2 = 0; it2 < 2; ++it2) {
+        w4_generic_finish(epi, smem, m0, ne, hh, tid, 2 * it2, bias8, qa);
+        if (it2 == 0) w4_generic_load(epi, m0, ne, hh, tid, 2, qa);
+        w4_generic_finish(epi, smem, m0, ne, hh, tid, 2 * it2 + 1, bias8, qb);
+        if (it2 == 0) w4_generic_load(epi, m0, ne, hh, tid, 3, qb);
+      }
+    } else {
+      w4_epilogue_rows(epi, smem, m0, n0, hh, tid);
+    }
     if (hh == 0) { O2_TS(3); } else { O2_TS(5); }
   }
 #ifdef O2_W4_STAMP

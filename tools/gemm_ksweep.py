@@ -1,12 +1,10 @@
 """Per-tile fixed cost (prologue + epilogue) of the 256-tile kernels: time of [M, N] x K for a sweep of K, linear fit
-t = rounds * (t_fixed + nk * t_ktile).  argv: comma list of tile hints (default 256,266), library = lib/alt/w4probe.so."""
+t = rounds * (t_fixed + nk * t_ktile).  argv: comma list of tile hints (default 256,260)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "orbit-2_amd")]
 import torch
 from climate_learn import _hip
-if os.path.exists(os.path.join(ROOT, "orbit-2_amd", "lib", "alt", "w4probe.so")):
-    _hip.LIB_PATH = os.path.join(ROOT, "orbit-2_amd", "lib", "alt", "w4probe.so")
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(torch.bfloat16)
 def t(f, n=8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -14,7 +12,7 @@ def t(f, n=8):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-hints = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "256,266").split(",")]
+hints = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "256,260").split(",")]
 M, N = 65536, 9216
 rounds = (M // 256) * (N // 256) / 256.0
 Ks = (128, 256, 512, 1024, 2048, 3072)

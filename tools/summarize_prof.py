@@ -47,8 +47,10 @@ def pmc(path, out, unit_kb=("FETCH_SIZE", "WRITE_SIZE")):
 def traffic(fetch_csv, write_csv, out):
     """FETCH_SIZE / WRITE_SIZE passes -> per-launch HBM-side bytes per kernel family (JSON read by bench.py)."""
     import json
-    fam = {"gemm": ("gemm256t_kernel", "gemm256t_grouped_kernel", "gemm128_kernel", "gemm128_grouped_kernel"),
+    fam = {"gemm": ("gemm256t_kernel", "gemm256t_grouped_kernel", "gemm256w_kernel", "gemm256w_grouped_kernel", "gemm128_kernel",
+                    "gemm128_grouped_kernel"),
            "gemm_8phase_single": ("gemm256t_kernel",), "gemm_8phase_grouped_dw": ("gemm256t_grouped_kernel",),
+           "gemm_w4_single": ("gemm256w_kernel",), "gemm_w4_grouped_dw": ("gemm256w_grouped_kernel",),
            "attn_fwd": ("attn_fwd_kernel",),
            "attn_bwd_dq": ("attn_bwd_dq_kernel",), "attn_bwd_dkv": ("attn_bwd_dkv_kernel", "attn_bwd_dkv128_kernel")}
     acc = {k: {"FETCH_SIZE": [], "WRITE_SIZE": []} for k in fam}
