@@ -807,13 +807,15 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   else { voa = (uint32_t)((16 * (rr >> 1) + 4 * (rr & 1)) * lda + cp * 8) * 2u; pa0 = (uint32_t)(sk0 * lda) * 2u; psa = (uint32_t)lda * 2u; pha = 256u; ka = (uint32_t)(64 * lda) * 2u; }
   if (B_KC) { vob = (uint32_t)(pr * ldb + chunk * 8) * 2u; pb0 = (uint32_t)(wave * 32 * ldb) * 2u; psb = (uint32_t)(8 * ldb) * 2u; phb = (uint32_t)(128 * ldb) * 2u; kb = 128u; }
   else { vob = (uint32_t)((16 * (rr >> 1) + 4 * (rr & 1)) * ldb + cp * 8) * 2u; pb0 = (uint32_t)(sk0 * ldb) * 2u; psb = (uint32_t)ldb * 2u; phb = 256u; kb = (uint32_t)(64 * ldb) * 2u; }
-  const auto srda = __builtin_amdgcn_make_buffer_rsrc((void*)(A_KC ? A + (size_t)m0 * lda : A + m0), 0, 0x7fffffff, 0x00020000);
-  const auto srdb = __builtin_amdgcn_make_buffer_rsrc((void*)(B_KC ? B + (size_t)n0 * ldb : B + n0), 0, 0x7fffffff, 0x00020000);
+  // descriptor bases (the statement builds the descriptors and advances their bases along K: every per-lane / per-piece
+  // offset stays below 256 rows x row pitch)
+  const bf16_t* abase = A_KC ? A + (size_t)m0 * lda : A + m0;
+  const bf16_t* bbase = B_KC ? B + (size_t)n0 * ldb : B + n0;
   const uint32_t ldswa = lds0 + wave * 4 * (A_KC ? 1024 : 1056);
   const uint32_t ldswb = lds0 + 2 * O2_W4_UNIT + wave * 4 * (B_KC ? 1024 : 1056);
   const uint32_t nk = (uint32_t)(K / BK3);
 #define O2_W4_OPERANDS                                                                                                   \
-               [srda] "s"(srda), [srdb] "s"(srdb), [pa0] "s"(pa0), [psa] "s"(psa), [pha] "s"(pha), [pb0] "s"(pb0),       \
+               [abase] "s"(abase), [bbase] "s"(bbase), [pa0] "s"(pa0), [psa] "s"(psa), [pha] "s"(pha), [pb0] "s"(pb0),       \
                [psb] "s"(psb), [phb] "s"(phb), [ldswa] "s"(ldswa), [ldswb] "s"(ldswb), [nk] "s"(nk), [ka] "s"(ka),       \
                [kb] "s"(kb), [ta0] "v"(ta0), [ta1] "v"(ta1), [tb0] "v"(tb0), [tb1] "v"(tb1)
   if constexpr (!STAMP) {

@@ -94,6 +94,28 @@ def test_gemm_forms_4wave_kernel(hip, M, N, K, form):
         assert torch.equal(x, y)
 
 
+def test_gemm_4wave_kernel_operands_beyond_2GiB(hip):
+    """weight-gradient form at the size of the interm_1b batch-16 step: 131072 tokens x a 9216-wide K-strided operand = 2.4 GB, so
+    the last third of the contraction lies past 2^31 bytes from the operand's base -- the range of a buffer descriptor; the
+    kernel advances the descriptors' 48-bit bases along K (a 32-bit per-lane offset read zeros there: found in round 3 by
+    comparing with the 8-phase kernel at this size)"""
+    K, M, N = 131072, 256, 256
+    g = torch.Generator().manual_seed(9)
+    A = bf(torch.randn(K, 9216, generator=g) * 0.5).cuda()
+    B = bf(torch.randn(K, 256, generator=g) * 0.5).cuda()
+    outs = []
+    for tile in (260, 256):
+        o = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(A[:, 9216 - M:], B, o, M, N, K, 9216, 256, N, a_kc=False, b_kc=False, tile=tile)   # the operand's LAST columns
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = A[K - 4096:, 9216 - M:].float().t() @ B[K - 4096:].float()                                  # the tail alone is non-zero
+    tail = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(A[K - 4096:, 9216 - M:], B[K - 4096:], tail, M, N, 4096, 9216, 256, N, a_kc=False, b_kc=False, tile=260)
+    assert nerr(tail, ref.cpu()) < 2e-5
+
+
 def test_gemm_4wave_kernel_takes_whole_tiles_only(hip):
     A, B = bf(torch.randn(264, 128)).cuda(), bf(torch.randn(256, 128)).cuda()
     out = torch.empty(264, 256, dtype=torch.bfloat16, device="cuda")

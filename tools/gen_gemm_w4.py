@@ -33,7 +33,7 @@ YB = lambda j: 224 + 4 * j
 V4 = lambda b: "v[%d:%d]" % (b, b + 3)
 V2 = lambda b: "v[%d:%d]" % (b, b + 1)
 A4 = lambda b: "a[%d:%d]" % (b, b + 3)
-S_PA, S_PB, S_WA, S_T, S_X, S_M0, S_X2, S_WB, S_TA, S_TB = 64, 72, 80, 81, 82, 83, 84, 85, 86, 87
+S_PA, S_PB, S_WA, S_T, S_X, S_M0, S_X2, S_WB, S_TA, S_TB, S_DA, S_DB = 64, 72, 80, 81, 82, 83, 84, 85, 86, 87, 88, 92
 
 
 def frag_reads(op, kc, regs, kk):
@@ -57,21 +57,25 @@ def tile_loads(a_kc, b_kc):
         for t in range(4):
             if which < 2:
                 setm0 = "s_add_u32 m0, s%d, %d" % (S_WA, h * UNIT + t * (1024 if a_kc else 1056))
-                ld = "buffer_load_dwordx4 %%[voa], %%[srda], s%d offen lds" % (S_PA + h * 4 + t)
+                ld = "buffer_load_dwordx4 %%[voa], s[%d:%d], s%d offen lds" % (S_DA, S_DA + 3, S_PA + h * 4 + t)
             else:
                 setm0 = "s_add_u32 m0, s%d, %d" % (S_WB, h * UNIT + t * (1024 if b_kc else 1056))
-                ld = "buffer_load_dwordx4 %%[vob], %%[srdb], s%d offen lds" % (S_PB + h * 4 + t)
+                ld = "buffer_load_dwordx4 %%[vob], s[%d:%d], s%d offen lds" % (S_DB, S_DB + 3, S_PB + h * 4 + t)
             out.append((setm0, ld, which >= 2))
     return out
 
 
 def k_advance(first):
+    """the K advance moves the 48-bit BASE of the two buffer descriptors (SALU): the 32-bit per-lane offset of a K-strided
+    operand would pass 2^31 -- the descriptors' range -- at K x row pitch x 2 B > 2 GiB (131072 tokens x 9216 columns)"""
     return first + [
         "s_cmp_lt_u32 s%d, %%[nk]" % S_X,
         "s_cselect_b32 s%d, %%[kb], 0" % S_X2,
         "s_cselect_b32 s%d, %%[ka], 0" % S_X,
-        "v_add_u32 %%[voa], s%d, %%[voa]" % S_X,
-        "v_add_u32 %%[vob], s%d, %%[vob]" % S_X2,
+        "s_add_u32 s%d, s%d, s%d" % (S_DA, S_DA, S_X),
+        "s_addc_u32 s%d, s%d, 0" % (S_DA + 1, S_DA + 1),
+        "s_add_u32 s%d, s%d, s%d" % (S_DB, S_DB, S_X2),
+        "s_addc_u32 s%d, s%d, 0" % (S_DB + 1, S_DB + 1),
     ]
 
 
@@ -90,6 +94,10 @@ def gen(a_kc, b_kc, cfg):
             e("s_add_u32 s%d, s%d, %s" % (S + t, S + t - 1, ps))
         for t in range(4):
             e("s_add_u32 s%d, s%d, %s" % (S + 4 + t, S + t, ph))
+    for S, base in ((S_DA, "%[abase]"), (S_DB, "%[bbase]")):          # raw buffer descriptors: base, stride 0, 2^31 - 1 bytes
+        e("s_mov_b64 s[%d:%d], %s" % (S, S + 1, base))
+        e("s_mov_b32 s%d, 0x7fffffff" % (S + 2))
+        e("s_mov_b32 s%d, 0x00020000" % (S + 3))
     e("s_mov_b32 s%d, %%[ldswa]" % S_WA)
     e("s_mov_b32 s%d, %%[ldswb]" % S_WB)
     e("s_lshl_b32 s%d, s%d, 1" % (S_TA, S_WA))               # stage flip of a write base: base <- (2 base0 + STAGE) - base
@@ -155,9 +163,9 @@ def gen(a_kc, b_kc, cfg):
     ka_ = k_advance(["s_add_u32 s%d, s%d, 3" % (S_X, S_T)])
     ga = max(lg) + 1
     assert ga + 3 <= 125, "pieces run too late"
-    gaps[ga] += ka_[:4]                          # scalar part (s_cmp + s_cselects stay together: SCC)
-    gaps[ga + 1] += ka_[4:5]
-    gaps[ga + 2] += ka_[5:6]
+    gaps[ga] += ka_[:4]                          # s_cmp + s_cselects stay together (SCC)
+    gaps[ga + 1] += ka_[4:6]                     # s_add / s_addc pairs stay together (carry)
+    gaps[ga + 2] += ka_[6:8]
     gaps[ga + 3] += flip_write_bases()
     # X reads of K-tile t + 1
     g = b2 + 1
@@ -189,15 +197,19 @@ def gen(a_kc, b_kc, cfg):
             head[m] = "s_waitcnt lgkmcnt(%d)" % n
             done = last_needed + (outstanding - n)   # a clamped count retires younger reads too
     if cfg.get("stamp"):
+        # s[96:97] = the previous stamp, s[98:99] = this one; each point adds its distance to the previous one to %[tK]
+        def point(name):
+            return ["s_memtime s[98:99]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s98, s96" % S_X,
+                    "s_add_u32 %%[%s], %%[%s], s%d" % (name, name, S_X), "s_mov_b32 s96, s98"]
         k1 = next(k for k, x in enumerate(gaps[b1]) if x.startswith("s_waitcnt lgkmcnt"))
-        gaps[b1].insert(k1, "s_memtime s[90:91]")
+        gaps[b1][k1:k1] = point("t0")
         k1 = next(k for k, x in enumerate(gaps[b1]) if x.startswith("s_barrier"))
-        gaps[b1].insert(k1 + 1, "s_memtime s[92:93]")
+        gaps[b1][k1 + 1:k1 + 1] = point("t1")
         k2 = next(k for k, x in enumerate(gaps[b2]) if x.startswith("s_waitcnt vmcnt"))
-        gaps[b2].insert(k2, "s_memtime s[94:95]")
+        gaps[b2][k2:k2] = point("t2")
         k2 = next(k for k, x in enumerate(gaps[b2]) if x.startswith("s_barrier"))
-        gaps[b2].insert(k2 + 1, "s_memtime s[96:97]")
-        L.append("s_memtime s[88:89]")
+        gaps[b2][k2 + 1:k2 + 1] = point("t3")
+        L += ["s_memtime s[96:97]", "s_waitcnt lgkmcnt(0)"]
     for m in range(128):
         kk, i, j = m // 64, (m % 64) // 8, m % 8
         fa = (XA if kk == 0 else YA)(i)
@@ -208,11 +220,9 @@ def gen(a_kc, b_kc, cfg):
         L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (A4(acc), V4(fb), V4(fa), A4(acc)))
         L += gaps[m]
     if cfg.get("stamp"):
-        e("s_memtime s[98:99]")
-        e("s_waitcnt lgkmcnt(0)")
-        for k, name in enumerate(("t0", "t1", "t2", "t3", "t4")):
-            e("s_sub_u32 s%d, s%d, s%d" % (S_X, 90 + 2 * k, 88 + 2 * k))
-            e("s_add_u32 %%[%s], %%[%s], s%d" % (name, name, S_X))
+        for x in ["s_memtime s[98:99]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s98, s96" % S_X,
+                  "s_add_u32 %%[t4], %%[t4], s%d" % S_X]:
+            e(x)
     e("s_cmp_lt_u32 s%d, %%[nk]" % S_T)
     e("s_cbranch_scc1 o2w4_loop_%=")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
