@@ -116,6 +116,34 @@ def test_gemm_4wave_kernel_operands_beyond_2GiB(hip):
     assert nerr(tail, ref.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("name,M,N,K,a_kc,b_kc", [
+    ("fwd qkv", 131072, 9216, 3072, True, True), ("fwd fc2", 131072, 3072, 12288, True, True),
+    ("dX qkv", 131072, 3072, 9216, True, False), ("dX fc1", 131072, 3072, 12288, True, False),
+    ("dW qkv", 9216, 3072, 131072, False, False), ("dW fc1", 12288, 3072, 131072, False, False),
+    ("dW fc2", 3072, 12288, 131072, False, False)])
+def test_gemm_4wave_equals_8phase_at_the_bench_shapes(hip, name, M, N, K, a_kc, b_kc):
+    """the GEMM shapes of the interm_1b step at per-GPU batch 16 (131072 tokens; the hidden tensors with their padded row pitch):
+    two independently written kernels -- 64-bit global addresses in the 8-phase kernel, buffer descriptors in the 4-wave kernel --
+    must agree bit for bit at FULL size (operands of 2-3 GB; address arithmetic that only small shapes exercise is how the
+    round-3 descriptor-range defect got past the other tests)"""
+    pad = lambda n: n + 64 if (2 * n) % 8192 == 0 else n
+    g = torch.Generator(device="cuda").manual_seed(len(name) + M)
+    rnd = lambda r, c, ld: (torch.randn(r, ld, device="cuda", generator=g) * 0.5).to(torch.bfloat16)[:, :c]
+    A = rnd(M, K, pad(K)) if a_kc else rnd(K, M, pad(M))
+    B = rnd(N, K, K) if b_kc else rnd(K, N, pad(N))
+    outs = []
+    for tile in (260, 256):
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(A, B, o, M, N, K, A.stride(0), B.stride(0), N, a_kc=a_kc, b_kc=b_kc, tile=tile)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    rows = torch.tensor([0, M // 2 + 3, M - 1], device="cuda")           # and a few rows against fp32 arithmetic
+    a = (A[rows].float() if a_kc else A[:, rows].float().t())
+    ref = a @ (B.float().t() if b_kc else B.float())
+    assert nerr(outs[0][rows], ref.cpu()) < 6e-3
+
+
 def test_gemm_4wave_kernel_takes_whole_tiles_only(hip):
     A, B = bf(torch.randn(264, 128)).cuda(), bf(torch.randn(256, 128)).cuda()
     out = torch.empty(264, 256, dtype=torch.bfloat16, device="cuda")
