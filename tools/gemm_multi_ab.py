@@ -15,7 +15,7 @@ def t(f, n=5):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-D, T = 3072, 65536
+D, T = 3072, (131072 if "--b16" in sys.argv else 65536)
 cases = (("NT qkv", T, 3 * D, D, True, True), ("NT proj", T, D, D, True, True), ("NN dXqkv", T, D, 3 * D, True, False),
          ("NN dXfc1", T, D, 4 * D, True, False), ("NN dXproj", T, D, D, True, False), ("TN dWfc1", 4 * D, D, T, False, False),
          ("TN dWqkv", 3 * D, D, T, False, False))
