@@ -144,6 +144,31 @@ def test_gemm_4wave_equals_8phase_at_the_bench_shapes(hip, name, M, N, K, a_kc, 
     assert nerr(outs[0][rows], ref.cpu()) < 6e-3
 
 
+def test_gemm_grouped_dw_4wave_equals_8phase_at_the_bench_size(hip):
+    """the weight-gradient group of one interm_1b Block at per-GPU batch 16 (131072 tokens; dY / X of the MLP with the padded row
+    pitch, 2.4-3.2 GB operands read K-strided): the grouped launch on the 4-wave kernel and on the 8-phase kernel, bit for bit"""
+    T, D = 131072, 3072
+    pad = lambda n: n + 64 if (2 * n) % 8192 == 0 else n
+    g = torch.Generator(device="cuda").manual_seed(21)
+    rnd = lambda c: (torch.randn(T, pad(c), device="cuda", generator=g) * 0.5).to(torch.bfloat16)[:, :c]
+    res = {}
+    shapes = ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D))
+    ops = [(rnd(no), rnd(ni)) for no, ni in shapes]
+    for hint in (258, 256):
+        probs = []
+        for (dy, x), (no, ni) in zip(ops, shapes):
+            out = torch.empty(no, ni, dtype=torch.bfloat16, device="cuda")
+            probs.append((dy, x, out, no, ni, T, dy.stride(0), x.stride(0), ni, dict(a_kc=False, b_kc=False, tile=hint)))
+        hip.gemm_grouped(probs)
+        torch.cuda.synchronize()
+        res[hint] = [p[2] for p in probs]
+    for a, b in zip(res[258], res[256]):
+        assert torch.equal(a, b)
+    dy, x = ops[2]                                                        # a few entries of dW fc1 against fp32 dot products
+    ref = dy[:, :4].float().t() @ x[:, :8].float()
+    assert nerr(res[258][2][:4, :8], ref.cpu()) < 6e-3
+
+
 def test_gemm_4wave_kernel_takes_whole_tiles_only(hip):
     A, B = bf(torch.randn(264, 128)).cuda(), bf(torch.randn(256, 128)).cuda()
     out = torch.empty(264, 256, dtype=torch.bfloat16, device="cuda")
