@@ -108,6 +108,48 @@ def test_attention_full_length_rows_and_identities(hip):
     assert float((o1.double() - out.double()).mean().abs()) < 1e-3
 
 
+def test_attention_at_the_bench_batch_last_sample(hip):
+    """per-GPU batch 16 (the bench's): qkv is 2.4 GB, so the last samples' rows lie past 2^31 bytes from its base -- sampled query
+    rows of sample 15 (out / lse / dQ, and dK / dV of sampled keys) against the fp64 row-wise restatement, and sample 15 computed
+    alone gives the same bits (batch independence across the 2 GiB line), with and without dropout"""
+    B, L, H, d = 16, L_, H_, 128
+    qkv = rnd(B, L, 3 * H * d, scale=0.7, seed=51)
+    do = rnd(B, L, H * d, seed=52)
+    out, lse = hip.attn_fwd(qkv, B, L, H, d, 0.0, 0)
+    dqkv = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, 0.0, 0)
+    b = B - 1
+    q5 = qkv.view(B, L, 3, H, d)
+    g = torch.Generator().manual_seed(9)
+    for _ in range(8):
+        h, q = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, L, (1,), generator=g))
+        qv, K, V = q5[b, q, 0, h].double(), q5[b, :, 1, h].double(), q5[b, :, 2, h].double()
+        s = (K @ qv) * d ** -0.5
+        pr = torch.softmax(s, 0)
+        o_ref = pr @ V
+        assert float((out.view(B, L, H, d)[b, q, h].double() - o_ref).abs().max() / o_ref.abs().max()) < 1.5e-2
+        assert abs(float(lse[b, h, q]) - float(torch.logsumexp(s, 0))) < 2e-3
+        dov = do.view(B, L, H, d)[b, q, h].double()
+        dp = V @ dov
+        ds = pr * (dp - (pr * dp).sum())
+        dq_ref = (ds @ K) * d ** -0.5
+        got = dqkv.view(B, L, 3, H, d)[b, q, 0, h].double()
+        assert float((got - dq_ref).abs().max() / dq_ref.abs().max()) < 3e-2
+    one = qkv[b:b + 1].contiguous()
+    for p, seed in ((0.0, 0), (0.1, 77)):
+        if p:
+            out, lse = hip.attn_fwd(qkv, B, L, H, d, p, seed)
+            dqkv = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, seed)
+        if p == 0.0:                                   # (with dropout the masks are a function of the global row index b*H*L ...)
+            o1, l1 = hip.attn_fwd(one, 1, L, H, d, p, seed)
+            d1 = hip.attn_bwd(one, o1, do[b:b + 1].contiguous(), l1, 1, L, H, d, p, seed)
+            assert torch.equal(o1[0], out[b]) and torch.equal(l1[0], lse[b]) and torch.equal(d1[0], dqkv[b])
+        else:
+            o2, l2 = hip.attn_fwd(qkv, B, L, H, d, p, seed)
+            assert torch.equal(o2, out) and torch.equal(l2, lse)
+            dv_sum = dqkv.view(B, L, 3, H, d)[b, :, 2].double().sum(0)
+            assert torch.isfinite(dv_sum).all()
+
+
 def test_layernorm_adamw_sampled(hip):
     x = rnd(M_, D_, scale=2.0, seed=41)
     gam, bet = rnd(D_, seed=42), rnd(D_, seed=43)
