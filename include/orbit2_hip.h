@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ORBIT2_ABI_VERSION 2
+#define ORBIT2_ABI_VERSION 3
 int orbit2_abi_version(void);
 
 /* ---- bf16 MFMA GEMM with fused epilogue ------------------------------------------------
@@ -28,8 +28,8 @@ int orbit2_abi_version(void);
  * Replaces every nn.Linear on the path: attention.py:36,40,50,81; mlp.py:50,54,63,67;
  * res_slimvit.py:115-120,326 (head); var_agg.proj attention.py:129,177 -- forward (a_kc=b_kc=1),
  * input-gradient (a_kc=1,b_kc=0) and weight-gradient (a_kc=b_kc=0) forms.
- * Epilogue order: +bias -> *colscale (columns n < colscale_n) -> save_pre -> GELU -> [+residual if res_first] -> dropout ->
- *   *gelu'(dgelu_pre) -> *rowscale[m / rows_per_scale] -> [+residual] -> C = beta*C + v.
+ * Epilogue order: +bias -> *colscale (columns n < colscale_n) -> save_pre -> GELU -> [+residual if res_first] -> dropout
+ *   [-> save_dact] -> *gelu'(dgelu_pre) -> *mul -> *rowscale[m / rows_per_scale] -> [+residual] -> C = beta*C + v.
  * Requirements: N % 8 == 0; M % 8 == 0 unless a_kc (any M then); K % 8 == 0 if an operand is K-contiguous, any K when
  * both are K-strided (the weight-gradient form: K = tokens); lda/ldb/ldc % 8 == 0, 16-byte aligned bases. */
 typedef struct {
@@ -53,6 +53,12 @@ typedef struct {
                               260 = 4-wave kernel (M, N % 256 == 0, K % 64 == 0) */
   int colscale_n;          /* columns n < colscale_n (a multiple of 8; 0 = none) are multiplied by colscale in fp32 right after */
   float colscale;          /*   the bias: the qkv Linear stores q * log2(e)/sqrt(d) (attention.py:50,54: q * scale), rounded ONCE */
+  void* save_dact;         /* int16 [M][ldc] or NULL (needs act == 1): GELU'(pre) x (kept ? 1 / (1 - p) : 0) of THIS element as signed
+                              fixed point with 14 fraction bits (the factor lies in [-0.15, 1.26]: 3e-5 absolute, where bf16 would
+                              give 4e-3) -- what the backward multiplies the input gradient by (autograd of mlp.py:64-65), computed
+                              here, where the pre-activation and the dropout decision are in registers, instead of GELU' + the
+                              mask again in the backward */
+  const void* mul;         /* int16 q14 [M][ldc] or NULL: multiply the result elementwise (the backward's use of a save_dact tensor) */
 } orbit2_gemm_args;
 int orbit2_gemm_bf16(const orbit2_gemm_args* args, void* stream);
 

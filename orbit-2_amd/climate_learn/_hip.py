@@ -43,6 +43,8 @@ class GemmArgs(C.Structure):
         ("tile_hint", C.c_int),
         ("colscale_n", C.c_int),
         ("colscale", C.c_float),
+        ("save_dact", C.c_void_p),
+        ("mul", C.c_void_p),
     ]
 
 
@@ -55,7 +57,7 @@ def lib():
                 "liborbit2_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        if _lib.orbit2_abi_version() != 2:
+        if _lib.orbit2_abi_version() != 3:
             raise HipBackendError("liborbit2_hip.so ABI version mismatch")
     return _lib
 
@@ -121,7 +123,7 @@ timer: Optional[KernelTimer] = None
 # ------------------------------------------------------------------------------------------------
 def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, act=0, save_pre=None,
                dgelu_pre=None, drop_p=0.0, seed=0, rowscale=None, rows_per_scale=0, residual=None, ldr=0, res_mod=0,
-               res_first=False, beta=0.0, tile=0, colscale=None):
+               res_first=False, beta=0.0, tile=0, colscale=None, save_dact=None, mul=None):
     for t, nm in ((A, "A"), (B, "B")):
         _dev_rows(t, BF, nm)
     if out.dtype not in (BF, F32) or not out.is_cuda:
@@ -142,6 +144,8 @@ def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=
     a.beta = float(beta)
     a.tile_hint = int(tile)
     a.colscale_n, a.colscale = (0, 1.0) if colscale is None else (int(colscale[0]), float(colscale[1]))
+    a.save_dact = None if save_dact is None else _dev_rows(save_dact, BF, "save_dact").data_ptr()    # row pitch = ldc
+    a.mul = None if mul is None else _dev_rows(mul, BF, "mul").data_ptr()                            # row pitch = ldc
     return 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0)
 
 

@@ -149,6 +149,19 @@ def _needs(ctx, i):
     return ctx.needs_input_grad[i]
 
 
+# GELU layers: True = the forward epilogue stores GELU'(pre) x dropout factor (save_dact) and the backward multiplies by it (mul);
+# False = round 2's form (the forward stores the pre-activation, the backward epilogue evaluates GELU' and the mask again)
+_DACT = True
+
+
+def _gelu_fwd_kw(buf, p, seed):
+    return dict(act=1, save_dact=buf, drop_p=p, seed=seed) if _DACT else dict(act=1, save_pre=buf, drop_p=p, seed=seed)
+
+
+def _gelu_bwd_kw(buf, p, seed):
+    return dict(mul=buf) if _DACT else dict(drop_p=p, seed=seed, dgelu_pre=buf)
+
+
 def _ld_pad(n: int) -> int:
     """row pitch (elements) of a [rows, n] bf16 activation that only GEMMs and column sums touch: rows a multiple of 8 KiB apart
     put the same k-offset of EVERY row on the same memory channel (the MLP hidden tensors of interm_1b: 24 KiB rows) and the
@@ -308,8 +321,12 @@ class BlockFn(torch.autograd.Function):
             _tp.all_reduce_sum(part, grp)
             x1 = _hip.post_reduce(part, M, D, residual=x2d, rowscale=dp1, rows_per_scale=L)
         h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b))
-        pre = _rows(M, hid, x2d.device)           # the hidden tensors (pre, hm, and dpre in backward) carry _ld_pad's row pitch
-        hm = _linear_fwd(h2, w1, b1, M, hid, D, pad=True, act=1, save_pre=pre, drop_p=p_mlp, seed=s1)
+        # the hidden tensors (pre, hm, and dpre in backward) carry _ld_pad's row pitch.  `pre` holds what the backward multiplies
+        # by -- GELU'(pre-activation) x dropout factor, computed in fc1's epilogue where both are in registers (save_dact) --
+        # not the pre-activation itself: the fc2 input gradient then has a one-multiply epilogue (4-wave kernel) instead of
+        # GELU' + the mask again (reference: autograd of mlp.py:64-65)
+        pre = _rows(M, hid, x2d.device)
+        hm = _linear_fwd(h2, w1, b1, M, hid, D, pad=True, **_gelu_fwd_kw(pre, p_mlp, s1))
         if grp is None:
             x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
                              residual=x1, ldr=D)
@@ -340,7 +357,7 @@ class BlockFn(torch.autograd.Function):
         dym2, gb2, done2 = _drop_bwd_bias(dx2, M, D, p_mlp, s2, dp2, L, b2)      # fc2's bias gradient rides along
         i2, gb2_ = dws.add(dym2, hm, w2, None if done2 else b2, M, D, hid)
         gb2 = gb2 if done2 else gb2_
-        dpre = _dx(dym2, w2, M, D, hid, pad=True, drop_p=p_mlp, seed=s1, dgelu_pre=pre)
+        dpre = _dx(dym2, w2, M, D, hid, pad=True, **_gelu_bwd_kw(pre, p_mlp, s1))
         del hm, pre, dym2
         i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D)
         dh2 = _dx(dpre, w1, M, hid, D)
@@ -400,7 +417,7 @@ class ChainFn(torch.autograd.Function):
             else:
                 s = seeds.next() if p_mid > 0 else 0
                 pre = torch.empty(M, N, dtype=BF, device=x.device)
-                y = _linear_fwd(h, W, b, M, N, K, act=1, save_pre=pre, drop_p=p_mid, seed=s)
+                y = _linear_fwd(h, W, b, M, N, K, **_gelu_fwd_kw(pre, p_mid, s))
                 saved += [h, pre]
             sds.append(s)
             h = y
@@ -439,7 +456,7 @@ class ChainFn(torch.autograd.Function):
                 grads[2 * i], grads[2 * i + 1] = _dw(g, h_in, W, b, M, N, K)
             if i > 0:
                 pre_prev = sv[2 * (i - 1) + 1]
-                g = _dx(g, W, M, N, K, drop_p=p_mid, seed=sds[i - 1], dgelu_pre=pre_prev)
+                g = _dx(g, W, M, N, K, **_gelu_bwd_kw(pre_prev, p_mid, sds[i - 1]))
             elif has_ln or ctx.needs_input_grad[0]:
                 g = _dx(g, W, M, N, K)
         if queued:

@@ -146,10 +146,30 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float y = o2_half_erfc_abs(x, e);
   return x * (x > 0.f ? 1.0f - y : y);
 }
+// GELU(x) and GELU'(x) from one evaluation of the shared terms (same expressions as gelu_fast / dgelu_fast: same bits)
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+  float e;
+  const float y = o2_half_erfc_abs(x, e);
+  const float cdf = x > 0.f ? 1.0f - y : y;
+  g = x * cdf;
+  dg = cdf + x * 0.3989422804014327f * e;
+}
 __device__ __forceinline__ float dgelu_fast(float x) {
   float e;
   const float y = o2_half_erfc_abs(x, e);
   return (x > 0.f ? 1.0f - y : y) + x * 0.3989422804014327f * e;
+}
+
+// the GELU-backward factor tensor (save_dact / mul): signed 16-bit fixed point, 14 fraction bits.  The factor lies in
+// [-0.15, 1.26] (GELU' in [-0.13, 1.13] times the dropout scale): q14 keeps it to 3e-5 where bf16 would keep 4e-3 near 1 --
+// the error of this factor goes un-averaged into the residual-gradient stream (tests/test_model_gpu.py: pos_embed).
+__device__ __forceinline__ unsigned pack_q14(float lo, float hi) {
+  const int a = __float2int_rn(lo * 16384.f), b = __float2int_rn(hi * 16384.f);
+  return ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+}
+__device__ __forceinline__ void unpack_q14(unsigned w, float& lo, float& hi) {
+  lo = (float)(int)(short)(w & 0xffffu) * (1.0f / 16384.f);
+  hi = (float)((int)w >> 16) * (1.0f / 16384.f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -80,6 +80,8 @@ struct Epi {
   float dscale, beta;
   int colscale_n;      // columns n < colscale_n are multiplied by colscale right after the bias (0: none)
   float colscale;
+  bf16_t* save_dact;   // GELU'(pre) x dropout factor of the element, for the backward (see include/orbit2_hip.h)
+  const bf16_t* mul;   // elementwise bf16 multiplier
 };
 
 __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
@@ -101,9 +103,20 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
     v[0] = bf2f((bf16_t)(o[0] & 0xffff)); v[1] = bf2f((bf16_t)(o[0] >> 16));
     v[2] = bf2f((bf16_t)(o[1] & 0xffff)); v[3] = bf2f((bf16_t)(o[1] >> 16));
   }
+  float dact[4] = {1.f, 1.f, 1.f, 1.f};
+  if (e.save_dact && !e.save_pre) {                   // GELU of the bf16-rounded pre-activation, as with save_pre
+    u32x2 o_; o_[0] = pack_bf2(v[0], v[1]); o_[1] = pack_bf2(v[2], v[3]);
+    v[0] = bf2f((bf16_t)(o_[0] & 0xffff)); v[1] = bf2f((bf16_t)(o_[0] >> 16));
+    v[2] = bf2f((bf16_t)(o_[1] & 0xffff)); v[3] = bf2f((bf16_t)(o_[1] >> 16));
+  }
   if (e.act == 1) {
+    if (e.save_dact) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+      for (int j = 0; j < 4; ++j) { float g_; gelu_both(v[j], g_, dact[j]); v[j] = g_; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+    }
   } else if (e.act == 2) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -123,7 +136,22 @@ __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
     const uint64_t idx = ((uint64_t)m * (uint64_t)e.N + (uint64_t)n) >> 2;
     const uint32_t h = o2_hash64(e.seed ^ o2_seed_salt, idx);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (((h >> (8 * j)) & 0xffu) >= e.thr) ? v[j] * e.dscale : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const bool keep = ((h >> (8 * j)) & 0xffu) >= e.thr;
+      v[j] = keep ? v[j] * e.dscale : 0.f;
+      dact[j] = keep ? dact[j] * e.dscale : 0.f;
+    }
+  }
+  if (e.save_dact) {
+    u32x2 o; o[0] = pack_q14(dact[0], dact[1]); o[1] = pack_q14(dact[2], dact[3]);
+    *reinterpret_cast<u32x2*>(e.save_dact + off) = o;
+  }
+  if (e.mul) {
+    const u32x2 mu = *reinterpret_cast<const u32x2*>(e.mul + off);
+    float m4[4];
+    unpack_q14(mu[0], m4[0], m4[1]); unpack_q14(mu[1], m4[2], m4[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= m4[j];
   }
   if (e.dgelu_pre) {
     const u32x2 pr = *reinterpret_cast<const u32x2*>(e.dgelu_pre + off);
@@ -184,6 +212,7 @@ __device__ __forceinline__ void epi8_load(const Epi& e, int m, int n, Pre8& q) {
     q.res = *reinterpret_cast<const u32x4*>(e.residual + (size_t)rm * e.ldr + n);
   }
   if (e.dgelu_pre) q.pre = *reinterpret_cast<const u32x4*>(e.dgelu_pre + off);
+  else if (e.mul) q.pre = *reinterpret_cast<const u32x4*>(e.mul + off);     // (never both: gemm_make_epi)
   if (e.beta != 0.f) q.old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(e.C) + off);
 }
 
@@ -203,9 +232,18 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
     *reinterpret_cast<u32x4*>(e.save_pre + off) = o;
     unpack8(o, v);   // the backward recomputes GELU'(pre) from the ROUNDED value: round here too
   }
+  float dact[8];
+  // (GELU of the bf16-ROUNDED pre-activation, as with save_pre: the forward's bits do not depend on which of the two the
+  // caller asked for)
+  if (e.save_dact && !e.save_pre) { const u32x4 o_ = pack8(v); unpack8(o_, v); }
   if (e.act == 1) {
+    if (e.save_dact) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+      for (int k = 0; k < 8; ++k) gelu_both(v[k], v[k], dact[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+    }
   } else if (e.act == 2) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -224,8 +262,25 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
     for (int hlf = 0; hlf < 2; ++hlf) {
       const uint32_t h = o2_hash64(e.seed ^ o2_seed_salt, idx + hlf);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 * hlf + j] = (((h >> (8 * j)) & 0xffu) >= e.thr) ? v[4 * hlf + j] * e.dscale : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const bool keep = ((h >> (8 * j)) & 0xffu) >= e.thr;
+        v[4 * hlf + j] = keep ? v[4 * hlf + j] * e.dscale : 0.f;
+        if (e.save_dact) dact[4 * hlf + j] = keep ? dact[4 * hlf + j] * e.dscale : 0.f;
+      }
     }
+  }
+  if (e.save_dact) {
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack_q14(dact[2 * k], dact[2 * k + 1]);
+    *reinterpret_cast<u32x4*>(e.save_dact + off) = o;
+  }
+  if (e.mul) {
+    float m8[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) unpack_q14(q.pre[k], m8[2 * k], m8[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= m8[k];
   }
   if (e.dgelu_pre) {
     float p8[8];
@@ -700,7 +755,7 @@ __device__ __forceinline__ void w4_epilogue_rows(const Epi& epi, const char* sme
   // lean path (bias / column scale only; whole tiles by construction of this kernel): per 8 values two LDS reads, the adds
   // and multiplies of epi8_finish in its order (bit-identical), four conversions and one 16-byte store
   const bool lean = !epi.out_fp32 && !epi.save_pre && epi.act == 0 && !epi.residual && epi.thr == 0 && !epi.dgelu_pre &&
-                    !epi.rowscale && epi.beta == 0.f;
+                    !epi.rowscale && epi.beta == 0.f && !epi.mul;
   if (lean) {
     const float mul = n < epi.colscale_n ? epi.colscale : 1.0f;
     const int r8 = tid >> 5;
@@ -733,24 +788,24 @@ __device__ __forceinline__ void w4_epilogue_rows(const Epi& epi, const char* sme
   }
 }
 
-// generic bf16 epilogue of the 4-wave kernel (any combination of Epi's options): four image rows per step and lane, the
+// generic bf16 epilogue of the 4-wave kernel (any combination of Epi's options): two image rows per step and lane, the
 // loads (residual / pre-activation / old C) two steps ahead of their use -- the first two steps' loads are issued BEFORE the
 // accumulators are staged through LDS: with one wave per SIMD nobody else hides their latency (at one step ahead the
 // epilogue ran at the ~2 TB/s its 32 KB in flight per CU allow)
 __device__ __forceinline__ int w4_row_m(int m0, int hh, int tid, int it, int k) {
-  const int lr = (it * 4 + k) * 8 + (tid >> 5);
+  const int lr = (it * 2 + k) * 8 + (tid >> 5);
   return m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
 }
-__device__ __forceinline__ void w4_generic_load(const Epi& epi, int m0, int n, int hh, int tid, int it, Pre8 (&pq)[4]) {
+__device__ __forceinline__ void w4_generic_load(const Epi& epi, int m0, int n, int hh, int tid, int it, Pre8 (&pq)[2]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) epi8_load(epi, w4_row_m(m0, hh, tid, it, k), n, pq[k]);
+  for (int k = 0; k < 2; ++k) epi8_load(epi, w4_row_m(m0, hh, tid, it, k), n, pq[k]);
 }
 __device__ __forceinline__ void w4_generic_finish(const Epi& epi, const char* smem, int m0, int n, int hh, int tid, int it,
-                                                  const float* bias8, const Pre8 (&pq)[4]) {
+                                                  const float* bias8, const Pre8 (&pq)[2]) {
   const int q = tid & 31;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int lr = (it * 4 + k) * 8 + (tid >> 5);
+  for (int k = 0; k < 2; ++k) {
+    const int lr = (it * 2 + k) * 8 + (tid >> 5);
     const char* row = smem + lr * 1024;
     const int sw = lr & 7;
     const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ sw) << 4));
@@ -857,7 +912,7 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   const uint32_t crow = lds0 + (uint32_t)(wm * 64 + u) * 1024u;
   const uint32_t be = crow + (uint32_t)(((wn * 32 + cg) ^ sw) << 4), bo = crow + (uint32_t)(((wn * 32 + 4 + cg) ^ sw) << 4);
   const bool lean = !epi.out_fp32 && !epi.save_pre && epi.act == 0 && !epi.residual && epi.thr == 0 && !epi.dgelu_pre &&
-                    !epi.rowscale && epi.beta == 0.f;
+                    !epi.rowscale && epi.beta == 0.f && !epi.mul;
   const bool generic = !lean && !epi.out_fp32;
   const int ne = n0 + 8 * (tid & 31);
   float bias8[8];
@@ -866,7 +921,7 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   if (generic && epi.bias) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
 #pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
-    Pre8 qa[4], qb[4];
+    Pre8 qa[2], qb[2];
     if (generic) {
       w4_generic_load(epi, m0, ne, hh, tid, 0, qa);
       w4_generic_load(epi, m0, ne, hh, tid, 1, qb);
@@ -878,11 +933,11 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
     if (hh == 0) { O2_TS(2); } else { O2_TS(4); }
     if (generic) {
 #pragma unroll 1
-      for (int it2 = 0; it2 < 2; ++it2) {
+      for (int it2 = 0; it2 < 4; ++it2) {
         w4_generic_finish(epi, smem, m0, ne, hh, tid, 2 * it2, bias8, qa);
-        if (it2 == 0) w4_generic_load(epi, m0, ne, hh, tid, 2, qa);
+        if (it2 < 3) w4_generic_load(epi, m0, ne, hh, tid, 2 * it2 + 2, qa);
         w4_generic_finish(epi, smem, m0, ne, hh, tid, 2 * it2 + 1, bias8, qb);
-        if (it2 == 0) w4_generic_load(epi, m0, ne, hh, tid, 3, qb);
+        if (it2 < 3) w4_generic_load(epi, m0, ne, hh, tid, 2 * it2 + 3, qb);
       }
     } else {
       w4_epilogue_rows(epi, smem, m0, n0, hh, tid);
@@ -1047,8 +1102,13 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (a->drop_p < 0.f || a->drop_p >= 1.f) return O2_ERR_ARG;
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
   if (a->colscale_n < 0 || a->colscale_n % 8) return O2_ERR_ARG;
+  if (a->save_dact && (a->act != 1 || a->out_fp32)) return O2_ERR_ARG;   // the factor of a GELU output element; bf16 path
+  if (a->mul && a->dgelu_pre) return O2_ERR_ARG;                           // one or the other (they share a load slot)
+  if (((uintptr_t)a->save_dact | (uintptr_t)a->mul) & 15) return O2_ERR_ARG;
   e.colscale_n = a->colscale_n;
   e.colscale = a->colscale;
+  e.save_dact = (bf16_t*)a->save_dact;
+  e.mul = (const bf16_t*)a->mul;
   e.bias = (const bf16_t*)a->bias;
   e.save_pre = (bf16_t*)a->save_pre;
   e.dgelu_pre = (const bf16_t*)a->dgelu_pre;

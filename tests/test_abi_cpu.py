@@ -17,13 +17,13 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export " + n
-    assert lib.orbit2_abi_version() == 2
+    assert lib.orbit2_abi_version() == 3
 
 
 def test_gemm_args_struct_matches_header():
     from climate_learn import _hip
     # field order/size contract with the C struct (8-byte pointers, 4-byte ints/floats, 8-byte seed)
-    assert ctypes.sizeof(_hip.GemmArgs) == 160
+    assert ctypes.sizeof(_hip.GemmArgs) == 176
     assert _hip.GemmArgs.seed.offset % 8 == 0
 
 

@@ -297,6 +297,23 @@ def test_gemm_epilogue_full(hip, tile, M, N):
     dgb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     hip.gemm(bf(A).cuda(), bf(W).cuda(), dgb, M, N, K, K, K, N, dgelu_pre=sp, drop_p=p, seed=seed, tile=tile)
     assert nerr(dgb, (A @ W.t()) * mask * sc * prq.grad) < 6e-3
+    # the same backward factor computed in the FORWARD (save_dact = GELU'(rounded pre) x dropout factor of the element) and
+    # applied by a one-multiply epilogue (mul): the forward output is the save_pre path's bit for bit (GELU of the bf16-rounded
+    # pre-activation either way), the product equals the dgelu path's up to the factor's 2^-15
+    out_d = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    dact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), out_d, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_dact=dact, drop_p=p,
+             seed=seed, rowscale=rs.cuda(), rows_per_scale=M // 4, residual=bf(res).cuda(), ldr=N, res_mod=L, tile=tile)
+    assert torch.equal(out_d, out)
+    dact_f = dact.view(torch.int16).float().cpu() / 16384.0          # (the factor tensor is int16 fixed point, 14 fraction bits)
+    assert nerr(dact_f, prq.grad * mask * sc) < 3e-3
+    dm = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), dm, M, N, K, K, K, N, mul=dact, tile=tile)
+    assert nerr(dm, (A @ W.t()) * dact_f) < 6e-3 and nerr(dm, dgb) < 8e-3
+    with pytest.raises(Exception):
+        hip.gemm(bf(A).cuda(), bf(W).cuda(), dm, M, N, K, K, K, N, mul=dact, dgelu_pre=sp, tile=tile)     # one or the other
+    with pytest.raises(Exception):
+        hip.gemm(bf(A).cuda(), bf(W).cuda(), dm, M, N, K, K, K, N, save_dact=dact, tile=tile)              # needs act = GELU
 
 
 @pytest.mark.parametrize("tile", [128, 256, 260])
