@@ -195,10 +195,28 @@ def _dx(dy2d, W, M, N, K, pad=False, **kw):
     return _hip.gemm(dy2d, cw(W), out, M, K, N, _ld(dy2d, N), K, out.stride(0), a_kc=True, b_kc=False, **kw)
 
 
+_DW_SPLIT = 8     # K-split of a weight gradient whose output is too few tiles to fill the chip (0: off)
+
+
+def _dw_split_ok(M, N, K):
+    """a lone weight gradient with < 192 tiles of 256 x 256 (the head's 192 x D output layer: 12; a D x D layer at D = 3072: 144)
+    and a long contraction (tokens): alone it runs on 48-144 workgroups for 2048 K-tiles; split over the tokens into _DW_SPLIT
+    partial products (ONE grouped launch, bf16 partials summed in fp32 in a fixed order: deterministic) it fills the chip"""
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    return _DW_SPLIT > 1 and tiles < 192 and M >= 32768 and M % (_DW_SPLIT * 64) == 0 and N % 8 == 0 and K % 8 == 0
+
+
 def _dw(dy2d, x2d, W, b, M, N, K):
     """dW[N,K] = dy^T . x ; db[N] = colsum(dy).  Returns what backward must return for (W, b)."""
     sw = _GradSink(W)
-    _hip.gemm(dy2d, x2d, sw.buf, N, K, M, _ld(dy2d, N), _ld(x2d, K), K, a_kc=False, b_kc=False, beta=sw.beta)
+    if _dw_split_ok(M, N, K) and dy2d.dim() == 2 and x2d.dim() == 2:
+        S, Mc = _DW_SPLIT, M // _DW_SPLIT
+        parts = torch.empty(S, N, K, dtype=BF, device=dy2d.device)     # bf16 partials, summed in fp32 by orbit2_batch_sum
+        _hip.gemm_grouped([(dy2d[i * Mc:(i + 1) * Mc], x2d[i * Mc:(i + 1) * Mc], parts[i], N, K, Mc, dy2d.stride(0), x2d.stride(0), K,
+                            dict(a_kc=False, b_kc=False)) for i in range(S)])
+        _hip.batch_sum(parts, S, N, K, sw.buf, beta=sw.beta)
+    else:
+        _hip.gemm(dy2d, x2d, sw.buf, N, K, M, _ld(dy2d, N), _ld(x2d, K), K, a_kc=False, b_kc=False, beta=sw.beta)
     gw = sw.done()
     gb = None
     if b is not None:

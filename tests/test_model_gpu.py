@@ -592,3 +592,23 @@ def test_block_padded_hidden_pitch_is_bit_identical(monkeypatch):
     plain = run(False)
     for a, b, c in zip(padded, plain, padded_rc):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_lone_weight_gradient_split_over_tokens(monkeypatch):
+    """_ops._dw splits a weight gradient whose output is too few tiles to fill the chip over the tokens (8 partial products in one
+    grouped launch, summed in fp32): same result as the single GEMM to the partials' bf16 rounding, with and without accumulation
+    into an existing gradient, and bit-reproducible"""
+    from climate_learn import _ops
+    M, N, K = 32768, 192, 1024
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dy = (torch.randn(M, N, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    x = (torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    W = torch.nn.Parameter(torch.zeros(N, K, device="cuda"))
+    assert _ops._dw_split_ok(M, N, K) and not _ops._dw_split_ok(M, 4096, 4096) and not _ops._dw_split_ok(4096, N, K)
+    ref = dy.float().t() @ x.float()
+    gw1, _ = _ops._dw(dy, x, W, None, M, N, K)
+    gw2, _ = _ops._dw(dy, x, W, None, M, N, K)
+    assert torch.equal(gw1, gw2) and nerr(gw1, ref.cpu()) < 8e-3
+    monkeypatch.setattr(_ops, "_DW_SPLIT", 0)
+    gw0, _ = _ops._dw(dy, x, W, None, M, N, K)
+    assert nerr(gw0, ref.cpu()) < 6e-3 and nerr(gw1, gw0.float().cpu()) < 8e-3
