@@ -54,8 +54,9 @@ typedef struct {
   int colscale_n;          /* columns n < colscale_n (a multiple of 8; 0 = none) are multiplied by colscale in fp32 right after */
   float colscale;          /*   the bias: the qkv Linear stores q * log2(e)/sqrt(d) (attention.py:50,54: q * scale), rounded ONCE */
   void* save_dact;         /* int16 [M][ldc] or NULL (needs act == 1): GELU'(pre) x (kept ? 1 / (1 - p) : 0) of THIS element as signed
-                              fixed point with 14 fraction bits (the factor lies in [-0.15, 1.26]: 3e-5 absolute, where bf16 would
-                              give 4e-3) -- what the backward multiplies the input gradient by (autograd of mlp.py:64-65), computed
+                              fixed point with 14 fraction bits, range [-2, 2), saturating (at drop_p = 0.1 the factor lies in
+                              [-0.15, 1.26]: 3e-5 absolute, where bf16 would give 4e-3; drop_p >= 0.434, where 1.13 / (1 - p)
+                              reaches 2, is refused with O2_ERR_UNSUPPORTED: use save_pre / dgelu_pre there) -- what the backward multiplies the input gradient by (autograd of mlp.py:64-65), computed
                               here, where the pre-activation and the dropout decision are in registers, instead of GELU' + the
                               mask again in the backward */
   const void* mul;         /* int16 q14 [M][ldc] or NULL: multiply the result elementwise (the backward's use of a save_dact tensor) */

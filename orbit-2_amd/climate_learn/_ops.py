@@ -154,12 +154,18 @@ def _needs(ctx, i):
 _DACT = True
 
 
+def _dact_ok(p):
+    """the q14 factor tensor holds [-2, 2): GELU' (<= 1.13) x the dropout scale 256 / (256 - round(256 p)) must stay inside
+    (orbit2_gemm_bf16 rejects save_dact otherwise); above drop_p ~ 0.43 the pre-activation form is used instead"""
+    return _DACT and 1.13 * 256.0 / (256.0 - int(p * 256.0 + 0.5)) < 2.0
+
+
 def _gelu_fwd_kw(buf, p, seed):
-    return dict(act=1, save_dact=buf, drop_p=p, seed=seed) if _DACT else dict(act=1, save_pre=buf, drop_p=p, seed=seed)
+    return dict(act=1, save_dact=buf, drop_p=p, seed=seed) if _dact_ok(p) else dict(act=1, save_pre=buf, drop_p=p, seed=seed)
 
 
 def _gelu_bwd_kw(buf, p, seed):
-    return dict(mul=buf) if _DACT else dict(drop_p=p, seed=seed, dgelu_pre=buf)
+    return dict(mul=buf) if _dact_ok(p) else dict(drop_p=p, seed=seed, dgelu_pre=buf)
 
 
 def _ld_pad(n: int) -> int:
@@ -209,7 +215,8 @@ def _dw_split_ok(M, N, K):
 def _dw(dy2d, x2d, W, b, M, N, K):
     """dW[N,K] = dy^T . x ; db[N] = colsum(dy).  Returns what backward must return for (W, b)."""
     sw = _GradSink(W)
-    if _dw_split_ok(M, N, K) and dy2d.dim() == 2 and x2d.dim() == 2:
+    # (an fp32 sink keeps the un-split path: the split's bf16 partials would round an fp32 gradient to 2^-9)
+    if _dw_split_ok(M, N, K) and dy2d.dim() == 2 and x2d.dim() == 2 and sw.buf.dtype == BF:
         S, Mc = _DW_SPLIT, M // _DW_SPLIT
         parts = torch.empty(S, N, K, dtype=BF, device=dy2d.device)     # bf16 partials, summed in fp32 by orbit2_batch_sum
         _hip.gemm_grouped([(dy2d[i * Mc:(i + 1) * Mc], x2d[i * Mc:(i + 1) * Mc], parts[i], N, K, Mc, dy2d.stride(0), x2d.stride(0), K,

@@ -163,8 +163,10 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 // the GELU-backward factor tensor (save_dact / mul): signed 16-bit fixed point, 14 fraction bits.  The factor lies in
 // [-0.15, 1.26] (GELU' in [-0.13, 1.13] times the dropout scale): q14 keeps it to 3e-5 where bf16 would keep 4e-3 near 1 --
 // the error of this factor goes un-averaged into the residual-gradient stream (tests/test_model_gpu.py: pos_embed).
+// pack_q14 SATURATES at the ends of [-2, 2): a factor outside it (GELU' up to 1.13 x a dropout scale >= 1.77, i.e. drop_p >= 0.434 --
+// rejected by gemm_make_epi) must never wrap to the opposite sign.
 __device__ __forceinline__ unsigned pack_q14(float lo, float hi) {
-  const int a = __float2int_rn(lo * 16384.f), b = __float2int_rn(hi * 16384.f);
+  const int a = min(max(__float2int_rn(lo * 16384.f), -32768), 32767), b = min(max(__float2int_rn(hi * 16384.f), -32768), 32767);
   return ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
 }
 __device__ __forceinline__ void unpack_q14(unsigned w, float& lo, float& hi) {

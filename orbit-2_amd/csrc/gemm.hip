@@ -1103,6 +1103,9 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   if (a->rowscale && a->rows_per_scale <= 0) return O2_ERR_ARG;
   if (a->colscale_n < 0 || a->colscale_n % 8) return O2_ERR_ARG;
   if (a->save_dact && (a->act != 1 || a->out_fp32)) return O2_ERR_ARG;   // the factor of a GELU output element; bf16 path
+  // save_dact stores GELU'(pre) x dropout scale as q14 fixed point, range [-2, 2): max GELU' = 1.129, so the scale must stay
+  // below 1.77 (drop_p < 0.434); above that the caller uses save_pre / dgelu_pre (climate_learn/_ops.py does)
+  if (a->save_dact && 1.13f * (256.0f / (256.0f - (float)(unsigned)(a->drop_p * 256.0f + 0.5f))) >= 2.0f) return O2_ERR_UNSUPPORTED;
   if (a->mul && a->dgelu_pre) return O2_ERR_ARG;                           // one or the other (they share a load slot)
   if (((uintptr_t)a->save_dact | (uintptr_t)a->mul) & 15) return O2_ERR_ARG;
   e.colscale_n = a->colscale_n;

@@ -317,6 +317,32 @@ def test_gemm_epilogue_full(hip, tile, M, N):
 
 
 @pytest.mark.parametrize("tile", [128, 256, 260])
+def test_gemm_save_dact_range(hip, tile):
+    """the q14 factor tensor (save_dact) holds [-2, 2): at drop_p = 0.4 (scale 1.67, factor up to 1.88) it is exact to 2^-15
+    and large positive pre-activations keep their sign; drop_p >= 0.434 (1.13 x scale >= 2 would wrap) is refused"""
+    M, N, K = 256, 256, 128
+    g = torch.Generator().manual_seed(15)
+    A, W = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.3)
+    bias = rt(torch.randn(N, generator=g) + 1.0)
+    p, seed = 0.4, 0x1234567
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    dact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(bf(A).cuda(), bf(W).cuda(), out, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_dact=dact, drop_p=p, seed=seed,
+             tile=tile)
+    pre = rt(A @ W.t() + bias).requires_grad_()
+    F.gelu(pre).sum().backward()
+    mask, sc = keep_mask(seed, M * N, p)
+    mask = torch.from_numpy(mask).view(M, N)
+    fac = dact.view(torch.int16).float().cpu() / 16384.0
+    want = pre.grad * mask * sc
+    assert want.max() > 1.8 and (fac - want).abs().max() < 2e-4          # no wrap: the largest factors keep their sign
+    for bad in (0.44, 0.5, 0.9):
+        with pytest.raises(Exception):
+            hip.gemm(bf(A).cuda(), bf(W).cuda(), out, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_dact=dact, drop_p=bad,
+                     seed=seed, tile=tile)
+
+
+@pytest.mark.parametrize("tile", [128, 256, 260])
 def test_gemm_column_scale(hip, tile):
     """colscale epilogue (the qkv Linear's q third times log2(e)/sqrt(d)): columns n < colscale_n are multiplied in fp32
     right after the bias -- one rounding to bf16 -- the rest are untouched bit for bit; fp32 and bf16 outputs"""

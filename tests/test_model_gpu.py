@@ -302,8 +302,11 @@ def test_graphed_step_captures_the_bucket_allreduces(monkeypatch):
             dist.destroy_process_group()
 
 
-def test_train_mode_step_matches_oracle_with_replicated_masks():
-    """The benchmark runs in TRAIN mode.  The reference's dropout RNG streams cannot be reproduced, but the kernels'
+@pytest.mark.parametrize("p_drop", [0.1, 0.5])
+def test_train_mode_step_matches_oracle_with_replicated_masks(p_drop):
+    """(p_drop = 0.5: GELU' x dropout scale leaves the q14 range of the save_dact factor, the Block / head fall back to the
+    pre-activation form -- climate_learn/_ops.py:_dact_ok -- and large positive pre-activations must keep their gradient sign.)
+    The benchmark runs in TRAIN mode.  The reference's dropout RNG streams cannot be reproduced, but the kernels'
     masks are pure functions of (seed, index): the test re-creates every mask of the step on the host (embedding
     dropout, attention-probability dropout, projection / MLP dropouts, DropPath) from the same seed sequence and feeds
     them to the CPU oracle as multipliers -- whole-model train-mode loss and gradients then have to agree."""
@@ -314,7 +317,7 @@ def test_train_mode_step_matches_oracle_with_replicated_masks():
     from climate_learn.trainer import training_step
     from tests.hashmask import attn_keep_mask, keep_mask, o2_hash64
     D, depth, heads, grid, B = 128, 3, 2, (16, 32), 2
-    p_drop, p_path = 0.1, 0.2
+    p_path = 0.2
     model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=D, depth=depth, heads=heads, grid=grid, B=B, seed=31)
     rates = torch.linspace(0, p_path, depth).tolist()
     for i, blk in enumerate(model.blocks):
