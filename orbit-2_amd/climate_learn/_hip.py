@@ -225,7 +225,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, beta_acc=0.0):
     return dx
 
 
-ATTN_4WAVES, ATTN_SPLIT_DKV, ATTN_Q_PRESCALED = 1, 2, 4      # include/orbit2_hip.h: kernel-variant flags of the *_ex attention entries (A/B, tests)
+ATTN_4WAVES, ATTN_SPLIT_DKV, ATTN_Q_PRESCALED, ATTN_NO_W4 = 1, 2, 4, 8      # include/orbit2_hip.h: kernel-variant flags of the *_ex attention entries (A/B, tests)
 
 
 def probe_read(buf, blocks, inflight, sink):

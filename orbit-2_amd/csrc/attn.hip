@@ -19,6 +19,7 @@
 #define O2_DKV256_LA 2      /* k-steps of LDS operands in flight in the d = 256 fused dK+dV kernel */
 #endif
 #include "../../include/orbit2_hip.h"
+#include "attn_fwd_asm.h"
 
 namespace {
 
@@ -511,6 +512,68 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
       w[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
       *reinterpret_cast<u32x2*>(orow + dd) = w;
     }
+}
+
+// =============================================================================================
+// forward, d = 128, q stored pre-scaled, L % 256 == 0: the GENERATED kernel (tools/gen_attn_fwd.py -> attn_fwd_asm.h)
+// =============================================================================================
+// One wave per SIMD with the whole register file; a wave owns 64 query rows as two 32-row blocks, the vector work of one block's
+// tile (exp2, row sums, dropout mask, bf16 packing) sits in the MFMA gaps of the other block's S / O products, every K / V
+// fragment read from LDS feeds two MFMAs, K / V tiles arrive by LDS-DMA one tile ahead of their first read, the softmax keeps a
+// fixed reference per row (guard + out-of-line fix-up).  The statement below is the whole kernel body: every instruction of it
+// is placed by the generator (its header describes the schedule); tools/cdna_emu.py executes the same text on the CPU
+// (tests/test_attn_asm_emu_cpu.py).  What the compiler contributes: the workgroup's coordinates, the key-group hash table of the
+// sequence (LDS, read by the dropout mask) and the lane's two row hashes.
+// Contract audited by tests/test_attn_asm_audit_cpu.py: no scratch, no spills, the statement's registers (v8-v255, a0-a255,
+// s36-s69) are clobbers so the descriptor allocates 512 registers per lane.
+#define O2_AF_MAX_L 16384
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int L, int H, unsigned thr, float dscale,
+                                                            uint64_t seed_arg) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(1024))) char smem[O2_AF_LDS_BYTES(O2_AF_MAX_L)];   // [2 slots][K 16 KiB | V 16 KiB] | key-group hashes
+  const uint64_t seed = seed_arg ^ o2_seed_salt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_i, head, b;
+  attn_tile_coords(L / 256, H, tile_i, head, b);
+  const int q0 = tile_i * 256 + wave * 64;
+  const size_t tstride = (size_t)3 * H * D;
+  if (DROP) {
+    // key-group hashes of the whole sequence (they depend on neither batch nor head): position T*16 + h*8 + j holds
+    // K(T*16 + 2 j + h), so lane half h reads the 8 values of its keys of tile T as two 16-byte pieces
+    uint32_t* skh = reinterpret_cast<uint32_t*>(smem + O2_AF_KH_OFF);
+    for (int i = tid; i < L / 4 + 16; i += 256) {
+      const uint32_t T = (uint32_t)i >> 4, wq = (uint32_t)i & 15;
+      skh[i] = o2_attn_keyhash(seed, T * 16 + 2 * (wq & 7) + (wq >> 3));
+    }
+  }
+  __syncthreads();
+  const char* kptr = reinterpret_cast<const char*>(qkv + (size_t)b * L * tstride + (size_t)H * D + (size_t)head * D);
+  const char* qptr = reinterpret_cast<const char*>(qkv + ((size_t)b * L + q0) * tstride + (size_t)head * D);
+  char* optr = reinterpret_cast<char*>(out + (((size_t)b * L + q0) * H + head) * D);
+  char* lptr = reinterpret_cast<char*>(lse + ((size_t)(b * H + head)) * L + q0);
+  const uint64_t row = (uint64_t)(b * H + head) * L + (uint64_t)(q0 + (lane & 31));
+  const uint32_t rhx = DROP ? o2_attn_rowhash(seed, row) : 0u, rhy = DROP ? o2_attn_rowhash(seed, row + 32) : 0u;
+  const uint32_t ldsb = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const int nt = L / 64, strideb = (int)(tstride * 2), hd2 = H * D * 2;
+  const uint32_t dsc = __float_as_uint(dscale);
+  if constexpr (DROP) {
+    asm volatile(O2_AF_ASM_DROP
+                 :
+                 : [kptr] "s"(kptr), [qptr] "s"(qptr), [optr] "s"(optr), [lptr] "s"(lptr), [nt] "s"(nt), [strideb] "s"(strideb),
+                   [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [dscale] "s"(dsc), [orowb] "s"(hd2),
+                   [rhx] "v"(rhx), [rhy] "v"(rhy)
+                 : O2_AF_CLOBBERS);
+  } else {
+    asm volatile(O2_AF_ASM_NODROP
+                 :
+                 : [kptr] "s"(kptr), [qptr] "s"(qptr), [optr] "s"(optr), [lptr] "s"(lptr), [nt] "s"(nt), [strideb] "s"(strideb),
+                   [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [dscale] "s"(dsc), [orowb] "s"(hd2),
+                   [rhx] "v"(rhx), [rhy] "v"(rhy)
+                 : O2_AF_CLOBBERS);
+  }
 }
 
 // =============================================================================================
@@ -1439,6 +1502,13 @@ extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B,
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
   hipStream_t s = (hipStream_t)stream;
+  if (d == 128 && (flags & ORBIT2_ATTN_Q_PRESCALED) && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L) {
+    dim3 grid((unsigned)((L / 256) * H * B)), block(256);
+    if (thr) hipLaunchKernelGGL((attn_fwd_w4_kernel<true>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed);
+    else hipLaunchKernelGGL((attn_fwd_w4_kernel<false>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
+  }
   const int nw = attn_waves_fwd(L, d, flags);
   const bool ragged = (L % (nw * 32)) != 0;
 #define O2_FWD(DV, NWV)                                                                              \

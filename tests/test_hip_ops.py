@@ -520,6 +520,66 @@ def test_attention_forced_late_rescale(hip, mult, min_jump_bits, prescaled):
     assert nerr(lse, torch.logsumexp(sc, -1)) < (1e-3 if prescaled else 3e-3)
 
 
+@pytest.mark.parametrize("H,L,B", [(2, 256, 1), (3, 512, 2), (1, 1024, 1), (2, 768, 2)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_fwd_generated_kernel(hip, H, L, B, p):
+    """d = 128, q pre-scaled, L % 256 == 0: the forward is the generated one-wave-per-SIMD kernel (csrc/attn_fwd_asm.h).  Against
+    the oracle with the kernels' own dropout mask, against the compiler-scheduled kernel (flag ORBIT2_ATTN_NO_W4: same math,
+    other summation order), bit-repeatable, and its lse drives the unchanged backward."""
+    d = 128
+    g = torch.Generator().manual_seed(17 * H + L)
+    stored, eff = _prescale_q(rt(torch.randn(B, L, 3 * H * d, generator=g)), B, L, H, d)
+    eff.requires_grad_()
+    do = rt(torch.randn(B, L, H * d, generator=g))
+    seed = 0x5EED0000 + L
+    mask, sc = None, 1.0
+    if p > 0:
+        m, sc = attn_keep_mask(seed, B * H, L, p)
+        mask = torch.from_numpy(m).view(B, H, L, L)
+    ref = _attn_ref(eff, B, L, H, d, mask, sc)
+    ref.backward(do)
+    sd = stored.cuda()
+    out, lse = hip.attn_fwd(sd, B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED)
+    old, lse_old = hip.attn_fwd(sd, B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED | hip.ATTN_NO_W4)
+    assert nerr(out, ref) < 1e-2
+    q, k, _ = eff.detach().view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    assert nerr(lse, torch.logsumexp((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1)) < 1e-3
+    assert nerr(out, old) < 8e-3 and float((lse - lse_old).abs().max()) < 1e-4
+    again, lse2 = hip.attn_fwd(sd, B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED)
+    assert torch.equal(out, again) and torch.equal(lse, lse2)
+    dqkv = hip.attn_bwd(sd, out, bf(do).cuda(), lse, B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED)
+    gr = eff.grad.view(B, L, 3, H * d)
+    dv = dqkv.view(B, L, 3, H * d)
+    for i, nm in enumerate("qkv"):
+        assert nerr(dv[:, :, i], gr[:, :, i]) < 2e-2, nm
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("mult", [60.0, 1200.0, 4000.0])
+def test_attention_fwd_generated_kernel_fixup(hip, mult, p):
+    """the generated forward keeps one reference per row (its maximum over the first 64 keys); a tile whose half-row sums leave
+    [0, 2^40] branches to the fix-up (reference moved, O / l rescaled, the tile's probabilities redone with the same dropout
+    mask).  One late key matches every query strongly: +11 bits (no fix-up), +66 bits, > 128 bits (exp2 gives inf first)."""
+    B, L, H, d = 1, 512, 2, 128
+    g = torch.Generator().manual_seed(78)
+    qkv = torch.randn(B, L, 3, H, d, generator=g) * 0.5
+    qkv[:, 300, 1] = qkv[:, :, 0].mean(1) * mult + 3.0
+    qkv[:, 450, 1] *= 12.0
+    stored, eff = _prescale_q(rt(qkv.reshape(B, L, 3 * H * d)), B, L, H, d)
+    seed = 31337
+    mask, sc = None, 1.0
+    if p > 0:
+        m, sc = attn_keep_mask(seed, B * H, L, p)
+        mask = torch.from_numpy(m).view(B, H, L, L)
+    ref = _attn_ref(eff, B, L, H, d, mask, sc)
+    out, lse = hip.attn_fwd(stored.cuda(), B, L, H, d, p, seed, flags=hip.ATTN_Q_PRESCALED)
+    q, k, _ = eff.view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    scr = (q * d ** -0.5) @ k.transpose(-2, -1)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert nerr(out, ref) < 1e-2
+    assert nerr(lse, torch.logsumexp(scr, -1)) < 1e-3
+
+
 @pytest.mark.parametrize("d,H,L,B", [(64, 2, 192, 2), (128, 3, 384, 1), (128, 2, 300, 1), (256, 1, 161, 1)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attention_q_prescaled(hip, d, H, L, B, p):
