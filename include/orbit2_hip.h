@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ORBIT2_ABI_VERSION 3
+#define ORBIT2_ABI_VERSION 4
 int orbit2_abi_version(void);
 
 /* ---- bf16 MFMA GEMM with fused epilogue ------------------------------------------------
@@ -127,9 +127,12 @@ int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const
  * attw: fp32 [B*L, H, V] softmax weights saved for backward.  patch must be 2. */
 int orbit2_varagg_fwd(const float* x, const float* stab, const float* gtab, void* z, float* attw, int B, int V,
                       int h, int w, int H, int D, void* stream);
-/* dstab/dgtab are ACCUMULATED into (caller zeroes them) */
+/* dstab/dgtab are ACCUMULATED into (caller zeroes them).  ws: fp32 workspace of orbit2_varagg_bwd_ws_floats(...) floats (ABI 4):
+ * every (head, token range) workgroup stores its partial tables in its own slab and the ranges are added in a fixed order --
+ * no float atomics, bitwise reproducible. */
+int64_t orbit2_varagg_bwd_ws_floats(int B, int V, int h, int w, int H, int D);
 int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
-                      float* dgtab, int B, int V, int h, int w, int H, int D, void* stream);
+                      float* dgtab, int B, int V, int h, int w, int H, int D, float* ws, void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------------------- */
 /* dym = dy * dropmask * rowscale (backward of the dropout/DropPath epilogue); dym may alias dy */
@@ -174,10 +177,13 @@ int orbit2_conv3x3_fwd(const float* in, const int* chan_idx, int in_ctotal, cons
                        float* out, float* pre, const float* addend, int Ha, int Wa, int B, int Cin, int Cout,
                        int H, int W, int mode, int r, void* stream);
 /* backward: dout is [B,Cout,H,W] (mode 0) or the shuffled [B,Cout/r^2,H*r,W*r] (mode 1, needs pre).
- * din (may be NULL) fp32 [B,Cin,H,W]; dweight/dbias fp32, ACCUMULATED into (caller zeroes). */
+ * din (may be NULL) fp32 [B,Cin,H,W]; dweight/dbias fp32, ACCUMULATED into (caller zeroes).
+ * ws: fp32 workspace of orbit2_conv3x3_bwd_ws_floats(...) floats (ABI 4): one slab of Cout*Cin*9 + Cout partial sums per
+ * 16x16-pixel tile, added in a fixed order (no float atomics: the gradients are bitwise reproducible). */
+int64_t orbit2_conv3x3_bwd_ws_floats(int B, int Cin, int Cout, int H, int W);
 int orbit2_conv3x3_bwd(const float* dout, const float* in, const int* chan_idx, int in_ctotal, const float* weight,
                        const float* pre, float* din, float* dweight, float* dbias, int B, int Cin, int Cout, int H,
-                       int W, int mode, int r, void* stream);
+                       int W, int mode, int r, float* ws, void* stream);
 /* in-place clamp of one channel at 0 (examples/intermediate_downscaling.py:267-272) */
 int orbit2_clamp_channel(float* img, int B, int C, int HW, int chan, void* stream);
 int orbit2_clamp_channel_bwd(const float* img_clamped, float* dimg, int B, int C, int HW, int chan, void* stream);
@@ -224,12 +230,15 @@ int orbit2_lpips_conv1_bwd(const void* dz, const float* w1, const float* pred, c
 /* LPIPS head of one tap.  feats: [2B][HW][C] bf16, images 0..B-1 = prediction, B..2B-1 = target; lin: fp32 [C].
  * fwd: val[b] += mean_px sum_c lin_c (f0_c/(|f0|+1e-10) - f1_c/(|f1|+1e-10))^2.   C in {64,128,256,512}.
  * bwd: gout[b][px][c] = coef * gscale[0] * d(sum_c ...)/d f0_c * (f0_c > 0)  -- the gradient w.r.t. the tap's PRE-ReLU output
- * (bf16; a pixel whose prediction features are all zero gets 0 where autograd of sqrt at 0 would produce NaN) */
-int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, void* stream);
+ * (bf16; a pixel whose prediction features are all zero gets 0 where autograd of sqrt at 0 would produce NaN)
+ * ws (fwd, ABI 4): fp32 workspace of orbit2_lpips_tap_ws_floats(B, HW, C) floats -- per-block partial sums added in a fixed order */
+int64_t orbit2_lpips_tap_ws_floats(int B, int HW, int C);
+int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, float* ws, void* stream);
 int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, const float* gscale, int B, int HW, int C,
                          void* stream);
-/* out[0] += mean |a - b|   (F.l1_loss, metrics/functional.py:30) */
-int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out[0] += mean |a - b|   (F.l1_loss, metrics/functional.py:30); ws: orbit2_l1_mean_ws_floats(n) floats (fixed-order sum, ABI 4) */
+int64_t orbit2_l1_mean_ws_floats(int64_t n);
+int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, float* ws, void* stream);
 
 /* ---- optimizer (utils/loaders.py:398-399 AdamW; ShardedGradScaler :732-742) ------------------ */
 /* flat fused AdamW over n elements: fp32 master p/m/v, gradient g (bf16 or fp32) multiplied by

@@ -57,7 +57,7 @@ def lib():
                 "liborbit2_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        if _lib.orbit2_abi_version() != 3:
+        if _lib.orbit2_abi_version() != 4:
             raise HipBackendError("liborbit2_hip.so ABI version mismatch")
     return _lib
 
@@ -297,12 +297,22 @@ def varagg_fwd(x, stab, gtab, H, D):
     return z, attw
 
 
+def _ws(query, args, device):
+    """fp32 workspace of a two-stage (slab + fixed-order combine) reduction: `query` is the entry's *_ws_floats function"""
+    query.restype = C.c_int64
+    n = int(query(*args))
+    if n <= 0:
+        raise HipBackendError("workspace query failed for %r" % (args,))
+    return torch.empty(n, dtype=F32, device=device)
+
+
 def varagg_bwd(x, gtab, attw, dz, H, D):
     _dev(x, F32, "x"); _dev(gtab, F32, "gtab"); _dev(attw, F32, "attw"); _dev(dz, BF, "dz")
     B, V, h, w = x.shape
     dstab = torch.zeros(H, V, 5, dtype=F32, device=x.device)
     dgtab = torch.zeros(V, 5, D, dtype=F32, device=x.device)
-    _chk(lib().orbit2_varagg_bwd(_p(x), _p(gtab), _p(attw), _p(dz), _p(dstab), _p(dgtab), B, V, h, w, H, D, _stream()),
+    ws = _ws(lib().orbit2_varagg_bwd_ws_floats, (B, V, h, w, H, D), x.device)
+    _chk(lib().orbit2_varagg_bwd(_p(x), _p(gtab), _p(attw), _p(dz), _p(dstab), _p(dgtab), B, V, h, w, H, D, _p(ws), _stream()),
          "orbit2_varagg_bwd")
     return dstab, dgtab
 
@@ -419,8 +429,9 @@ def conv3x3_bwd(dout, x, chan_idx, weight, pre, need_din, mode=0, r=1):
     din = torch.empty(B, Cin, H, W, dtype=F32, device=x.device) if need_din else None
     dw = torch.zeros_like(weight)
     db = torch.zeros(Cout, dtype=F32, device=x.device)
+    ws = _ws(lib().orbit2_conv3x3_bwd_ws_floats, (B, Cin, Cout, H, W), x.device)
     _chk(lib().orbit2_conv3x3_bwd(_p(dout), _p(x), _p(chan_idx), ctot, _p(weight), _p(pre), _p(din), _p(dw), _p(db), B,
-                                  Cin, Cout, H, W, mode, r, _stream()), "orbit2_conv3x3_bwd")
+                                  Cin, Cout, H, W, mode, r, _p(ws), _stream()), "orbit2_conv3x3_bwd")
     return din, dw, db
 
 
@@ -542,7 +553,8 @@ def lpips_conv1_bwd(dz, w1, pred, target, l1_coef, gscale=None):
 
 def lpips_tap_fwd(feats, lin, val, B, HW, Cc):
     _dev(feats, BF, "feats"); _dev(lin, F32, "lin"); _dev(val, F32, "val")
-    _chk(lib().orbit2_lpips_tap_fwd(_p(feats), _p(lin), _p(val), B, HW, Cc, _stream()), "orbit2_lpips_tap_fwd")
+    ws = _ws(lib().orbit2_lpips_tap_ws_floats, (B, HW, Cc), feats.device)
+    _chk(lib().orbit2_lpips_tap_fwd(_p(feats), _p(lin), _p(val), B, HW, Cc, _p(ws), _stream()), "orbit2_lpips_tap_fwd")
 
 
 def lpips_tap_bwd(feats, lin, coef, B, HW, Cc, gscale=None):
@@ -556,7 +568,8 @@ def lpips_tap_bwd(feats, lin, coef, B, HW, Cc, gscale=None):
 
 def l1_mean(a, b, out):
     _dev(a, F32, "a"); _dev(b, F32, "b"); _dev(out, F32, "out")
-    _chk(lib().orbit2_l1_mean(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "orbit2_l1_mean")
+    ws = _ws(lib().orbit2_l1_mean_ws_floats, (C.c_int64(a.numel()),), a.device)
+    _chk(lib().orbit2_l1_mean(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _p(ws), _stream()), "orbit2_l1_mean")
 
 
 def eval_moments(pred, target, lat_w=None, clim=None):

@@ -96,11 +96,12 @@ class HipDataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (),
                  is_lowp=None, sync_module_states: bool = True, overlap: bool = True,
                  shard_optimizer: bool = False, replica_group=None):
-        """replica_group: the tensor-parallel group of this rank (dist/tp.py).  The parameters that are NOT split
-        over it are replicas whose gradients agree only up to the summation order of the few atomic reductions
-        (conv weight gradients, variable-aggregation tables) -- and AdamW turns an ulp of difference in a near-zero
-        gradient into +-lr.  Their gradient ranges (laid out first inside every unit) are therefore overwritten
-        with the group's first rank's after the data-parallel reduction, which keeps the replicas bit-identical."""
+        """replica_group: the tensor-parallel group of this rank (dist/tp.py).  The parameters that are NOT split over it are
+        replicas.  Every kernel on their gradient path is bitwise reproducible (round 4: the conv weight / variable-aggregation
+        table gradients, once fp32 atomics, are two-stage fixed-order sums) and the ranks of a group see identical activations,
+        so the replicas' gradients agree bit for bit without any exchange -- the per-step broadcast from the group's first
+        rank that rounds 2-3 needed is gone; `replica_grad_views()` exposes the ranges (laid out first inside every unit) so
+        that tests can compare them across the group."""
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -259,7 +260,6 @@ class HipDataParallel(nn.Module):
                 if hasattr(p, "_o2g"):
                     p._o2_fresh = True
         self._launched = []
-        self._replicas_synced = False
 
     def _hi_hook(self, p):
         self.grad_ready(p)
@@ -360,11 +360,10 @@ class HipDataParallel(nn.Module):
                 cs.stalls.append((e0, e1))
             else:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
-        if self.replica_group is not None and not self._replicas_synced:
-            for bk in self.buckets:
-                for v in bk.rep_views:
-                    _tp.broadcast_first(v, self.replica_group)
-            self._replicas_synced = True
+
+    def replica_grad_views(self):
+        """gradient ranges of the parameters replicated over the tensor-parallel group (tests: equal on every rank of it)"""
+        return [v for bk in self.buckets for v in bk.rep_views]
 
     # ---- nn.Module surface -----------------------------------------------------------------------------
     def forward(self, *a, **k):

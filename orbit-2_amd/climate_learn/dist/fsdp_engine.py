@@ -62,14 +62,13 @@ class HipFullyShardedDataParallel(nn.Module):
         14-24).  The model then holds the rank's head / column slices; the shard and replicate groups are the data-parallel
         ranks of ONE tensor-parallel column, so chunks are cut from the rank's own slices and the tensor-parallel collectives of
         the model are untouched.  Parameters that are NOT split over tp_group (LayerNorms, embeddings, convolutions) are
-        replicas: laid out first inside every unit, their reduced gradients are overwritten with the group's first rank's
-        (as HipDataParallel does: atomics-ordered sums differ by an ulp, AdamW would turn that into +-lr)."""
+        replicas: laid out first inside every unit; their gradients agree bit for bit across the group without any exchange
+        (every kernel on their path is bitwise reproducible since round 4, see HipDataParallel)."""
         super().__init__()
         self.module = module
         self.pg = process_group
         self.tp_group = tp_group if (tp_group is not None and dist.is_initialized()
                                      and dist.get_world_size(tp_group) > 1) else None
-        self._replicas_synced = False
         self.rg = replicate_group if (replicate_group is not None and dist.get_world_size(replicate_group) > 1) else None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -403,7 +402,6 @@ class HipFullyShardedDataParallel(nn.Module):
     # ---- gradient life cycle -----------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
         self.g32.zero_()
-        self._replicas_synced = False
         for u in self.units:
             u.pending = sum(1 for p in u.params if p.requires_grad)
             u.handle = None
@@ -515,12 +513,6 @@ class HipFullyShardedDataParallel(nn.Module):
                 cs.stalls.append((e0, e1))
             else:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
-        if self.tp_group is not None and not self._replicas_synced:
-            from . import tp as _tp
-            for u in self.units:
-                for v in u.rep_views:
-                    _tp.broadcast_first(v, self.tp_group)
-            self._replicas_synced = True
 
     def gather_params(self):
         """after the local AdamW: the resident (root) unit's compute copies are re-assembled from the ranks' chunks; sharded

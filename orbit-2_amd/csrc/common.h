@@ -185,6 +185,37 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- two-stage sums (instead of float atomics): every producer workgroup stores its partial result in its own slab of a
+// caller-provided workspace, and this kernel adds the slabs in a FIXED order -- bitwise reproducible from launch to launch and
+// independent of how the workgroups were scheduled.  out[e] (+)= scale * sum_k parts[k * stride + e].
+// TPE = 1: one thread per element, parts in order (few parts, many elements); TPE = 32: 32 lanes per element, each sums
+// parts j, j + 32, ... in order, then a fixed shuffle tree (many parts, few elements).
+template <int TPE>
+static __global__ __launch_bounds__(256) void o2_sum_parts_kernel(const float* __restrict__ parts, int nparts, int64_t stride,
+                                                                  float* __restrict__ out, int64_t nelem, float scale,
+                                                                  int accumulate) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) / TPE;
+  const int j = threadIdx.x % TPE;
+  float s = 0.f;
+  if (e < nelem)
+    for (int k = j; k < nparts; k += TPE) s += parts[(size_t)k * stride + e];
+  if (TPE > 1) {
+#pragma unroll
+    for (int o = TPE / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  }
+  if (e < nelem && j == 0) out[e] = accumulate ? out[e] + s * scale : s * scale;
+}
+static inline void o2_sum_parts(const float* parts, int nparts, int64_t stride, float* out, int64_t nelem, float scale,
+                                int accumulate, hipStream_t s) {
+  if (nparts > 64) {
+    hipLaunchKernelGGL(o2_sum_parts_kernel<32>, dim3((unsigned)((nelem * 32 + 255) / 256)), dim3(256), 0, s, parts, nparts,
+                       stride, out, nelem, scale, accumulate);
+  } else {
+    hipLaunchKernelGGL(o2_sum_parts_kernel<1>, dim3((unsigned)((nelem + 255) / 256)), dim3(256), 0, s, parts, nparts, stride,
+                       out, nelem, scale, accumulate);
+  }
+}
+
 #define O2_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \

@@ -140,14 +140,18 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_kernel(const float* __re
 }
 
 // ---- weight / bias gradient: 16x16 pixel tile per block, one thread per (co, ci, tap) entry -------
+// Every block stores its Cout*Cin*9 + Cout partial sums in its own slab of `ws`; o2_sum_parts adds the slabs in a fixed
+// order (round 4: the fp32 atomics this replaced made the step's last digits differ from run to run).
 constexpr int TW = 16, TH = 16;
 __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __restrict__ dout,
                                                                  const float* __restrict__ pre,
                                                                  const float* __restrict__ in,
                                                                  const int* __restrict__ cidx, int in_ctotal,
-                                                                 float* __restrict__ dw, float* __restrict__ dbias,
+                                                                 float* __restrict__ ws,
                                                                  int B, int Cin, int Cout, int H, int W, int mode,
                                                                  int r) {
+  float* dw = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)Cout * Cin * 9 + Cout);
+  float* dbias = dw + (size_t)Cout * Cin * 9;
   __shared__ float sd[COB][TH][TW];
   __shared__ float si[CONV_MAXCIN][TH + 2][TW + 2];
   const int tiles_x = (W + TW - 1) / TW;
@@ -181,13 +185,13 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __
       for (int y = 0; y < TH; ++y)
 #pragma unroll
         for (int x = 0; x < TW; ++x) s = fmaf(sd[co][y][x], si[ci][y + ky][x + kx], s);
-      atomicAdd(dw + ((size_t)(co0 + co) * Cin + ci) * 9 + k, s);
+      dw[((size_t)(co0 + co) * Cin + ci) * 9 + k] = s;
     }
     for (int co = threadIdx.x; co < nco; co += 256) {
       float s = 0.f;
       for (int y = 0; y < TH; ++y)
         for (int x = 0; x < TW; ++x) s += sd[co][y][x];
-      atomicAdd(dbias + co0 + co, s);
+      dbias[co0 + co] = s;
     }
   }
 }
@@ -369,10 +373,15 @@ extern "C" int orbit2_conv3x3_fwd(const float* in, const int* chan_idx, int in_c
   return O2_OK;
 }
 
+extern "C" int64_t orbit2_conv3x3_bwd_ws_floats(int B, int Cin, int Cout, int H, int W) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  return (int64_t)B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * ((int64_t)Cout * Cin * 9 + Cout);
+}
+
 extern "C" int orbit2_conv3x3_bwd(const float* dout, const float* in, const int* chan_idx, int in_ctotal,
                                   const float* weight, const float* pre, float* din, float* dweight, float* dbias,
-                                  int B, int Cin, int Cout, int H, int W, int mode, int r, void* stream) {
-  if (!dout || !in || !weight || !dweight || !dbias || B <= 0 || Cin <= 0 || Cin > CONV_MAXCIN || Cout <= 0)
+                                  int B, int Cin, int Cout, int H, int W, int mode, int r, float* ws, void* stream) {
+  if (!dout || !in || !weight || !dweight || !dbias || !ws || B <= 0 || Cin <= 0 || Cin > CONV_MAXCIN || Cout <= 0)
     return O2_ERR_ARG;
   if (mode == 1 && (!pre || r <= 0 || Cout % (r * r))) return O2_ERR_ARG;
   if (mode != 0 && mode != 1) return O2_ERR_ARG;
@@ -383,8 +392,12 @@ extern "C" int orbit2_conv3x3_bwd(const float* dout, const float* in, const int*
     O2_CHECK_LAUNCH();
   }
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
-  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, grid, dim3(256), 0, s, dout, pre, in, chan_idx, in_ctotal, dweight,
-                     dbias, B, Cin, Cout, H, W, mode, r);
+  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, grid, dim3(256), 0, s, dout, pre, in, chan_idx, in_ctotal, ws,
+                     B, Cin, Cout, H, W, mode, r);
+  const int nparts = (int)(grid.x * grid.y);
+  const int64_t nw = (int64_t)Cout * Cin * 9, slab = nw + Cout;
+  o2_sum_parts(ws, nparts, slab, dweight, nw, 1.0f, 1, s);          // dweight / dbias += (as the atomics did)
+  o2_sum_parts(ws + nw, nparts, slab, dbias, Cout, 1.0f, 1, s);
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

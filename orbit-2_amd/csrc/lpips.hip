@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const bf16_t* __restrict
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(val + b, (red[0] + red[1] + red[2] + red[3]) / (float)HW);
+    if (threadIdx.x == 0) val[(size_t)blockIdx.x * B + b] = red[0] + red[1] + red[2] + red[3];     // the block's slab (forward: val = workspace)
   }
 }
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void l1_sum_kernel(const float* __restrict__ a
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // out = workspace: one partial per block
 }
 
 unsigned grid_for(int64_t work) {
@@ -355,11 +355,14 @@ extern "C" int orbit2_lpips_conv1_bwd(const void* dz, const float* w1, const flo
   return O2_OK;
 }
 
+static int lpips_tap_blocks(int HW, int C) {
+  int blocks = (HW * (C / 8) + 255) / 256;
+  return blocks > 1024 ? 1024 : blocks;
+}
 template <bool BWD>
 static int lpips_tap_launch(const void* f, const float* lin, float* val, void* gout, float coef, const float* gscale, int B,
                             int HW, int C, hipStream_t s) {
-  int blocks = (HW * (C / 8) + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  const int blocks = lpips_tap_blocks(HW, C);
   dim3 grid((unsigned)blocks, (unsigned)B), block(256);
 #define O2_TAP(G)                                                                                               \
   hipLaunchKernelGGL((lpips_tap_kernel<G, BWD>), grid, block, 0, s, (const bf16_t*)f, lin, val, (bf16_t*)gout, \
@@ -376,9 +379,20 @@ static int lpips_tap_launch(const void* f, const float* lin, float* val, void* g
   return O2_OK;
 }
 
-extern "C" int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, void* stream) {
-  if (!feats || !lin || !val || B <= 0 || HW <= 0) return O2_ERR_ARG;
-  return lpips_tap_launch<false>(feats, lin, val, nullptr, 0.f, nullptr, B, HW, C, (hipStream_t)stream);
+// forward sums: every block stores its partial in the workspace, the partials are added in a fixed order (round 4: these were
+// fp32 atomics; the loss value differed in its last digits from run to run)
+extern "C" int64_t orbit2_lpips_tap_ws_floats(int B, int HW, int C) {
+  if (B <= 0 || HW <= 0 || C <= 0) return 0;
+  return (int64_t)lpips_tap_blocks(HW, C) * B;
+}
+extern "C" int orbit2_lpips_tap_fwd(const void* feats, const float* lin, float* val, int B, int HW, int C, float* ws,
+                                    void* stream) {
+  if (!feats || !lin || !val || !ws || B <= 0 || HW <= 0) return O2_ERR_ARG;
+  const int rc = lpips_tap_launch<false>(feats, lin, ws, nullptr, 0.f, nullptr, B, HW, C, (hipStream_t)stream);
+  if (rc) return rc;
+  o2_sum_parts(ws, lpips_tap_blocks(HW, C), B, val, B, 1.0f / (float)HW, 1, (hipStream_t)stream);      // val[b] += mean over pixels
+  O2_CHECK_LAUNCH();
+  return O2_OK;
 }
 
 extern "C" int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* gout, float coef, const float* gscale, int B,
@@ -387,9 +401,12 @@ extern "C" int orbit2_lpips_tap_bwd(const void* feats, const float* lin, void* g
   return lpips_tap_launch<true>(feats, lin, nullptr, gout, coef, gscale, B, HW, C, (hipStream_t)stream);
 }
 
-extern "C" int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, void* stream) {
-  if (!a || !b || !out || n <= 0) return O2_ERR_ARG;
-  hipLaunchKernelGGL(l1_sum_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, 1.0f / (float)n);
+extern "C" int64_t orbit2_l1_mean_ws_floats(int64_t n) { return n > 0 ? (int64_t)grid_for(n) : 0; }
+extern "C" int orbit2_l1_mean(const float* a, const float* b, float* out, int64_t n, float* ws, void* stream) {
+  if (!a || !b || !out || !ws || n <= 0) return O2_ERR_ARG;
+  const unsigned nb = grid_for(n);
+  hipLaunchKernelGGL(l1_sum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, ws, n, 1.0f / (float)n);
+  o2_sum_parts(ws, (int)nb, 1, out, 1, 1.0f / (float)n, 1, (hipStream_t)stream);                        // out += mean |a - b|
   O2_CHECK_LAUNCH();
   return O2_OK;
 }

@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256, (DH == 256 ? 1 : 2)) void varagg_bwd_mfma_kern
   const int nchunk = (ntok + VM_T - 1) / VM_T;
   const int c0 = blockIdx.y * chunks_per_wg;
   const int c1 = min(nchunk, c0 + chunks_per_wg);
-  if (c0 >= c1) return;
+  if (c0 >= c1) return;                                       // (never: the launch gives every token range a chunk)
   const int NV5 = 5 * V;
+  // this token range's slabs of the workspace: [range][H][V][5] and [range][5V][D]; orbit2_varagg_bwd adds the ranges in order
+  dstab += (size_t)blockIdx.y * H * NV5;
+  dgtab += (size_t)blockIdx.y * NV5 * D;
   const int NB = (NV5 + 31) / 32;
   const bool wave_on = wave < NB;                             // wave <-> 32-row block of (v,c)
   const bf16_t* zbase = dz + (size_t)hh * DH;
@@ -393,27 +396,41 @@ __global__ __launch_bounds__(256, (DH == 256 ? 1 : 2)) void varagg_bwd_mfma_kern
     }
     __syncthreads();                                   // B4: chunk consumed; the images may be overwritten
   }
-  if (se < NV5) atomicAdd(dstab + ((size_t)hh * V + sv) * 5 + sc, sacc);
+  // the two token halves of the workgroup (threads se and se + 128) add in a fixed order through LDS, then one plain store
+  // into this workgroup's slab
+  if (se < NV5 && shalf == 1) dsv[se] = sacc;
+  __syncthreads();
+  if (se < NV5 && shalf == 0) dstab[((size_t)hh * V + sv) * 5 + sc] = sacc + dsv[se];
   if (wave_on) {
 #pragma unroll
     for (int db = 0; db < NDBZ; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;
-        if (row < NV5) atomicAdd(dgtab + (size_t)row * D + (size_t)hh * DH + db * 32 + (lane & 31), acc[db][r]);
+        if (row < NV5) dgtab[(size_t)row * D + (size_t)hh * DH + db * 32 + (lane & 31)] = acc[db][r];
       }
   }
 }
 
-template <int DH>
-static void varagg_bwd_mfma_launch(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
-                                   float* dgtab, int B, int V, int h, int w, int H, int D, int ntok, hipStream_t s) {
+// token ranges of the MFMA backward: ~3 workgroups per CU over (heads x ranges)
+static int varagg_bwd_splits(int ntok, int H, int* cpw_out) {
   const int nchunk = (ntok + VM_T - 1) / VM_T;
-  // ~3 workgroups per CU over (heads x token ranges); each range amortises one 5V x dh atomic flush
   int splits = (768 + H - 1) / H;
   if (splits > nchunk) splits = nchunk;
   const int cpw = (nchunk + splits - 1) / splits;
-  splits = (nchunk + cpw - 1) / cpw;
+  if (cpw_out) *cpw_out = cpw;
+  return (nchunk + cpw - 1) / cpw;
+}
+
+template <int DH>
+static void varagg_bwd_mfma_launch(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
+                                   float* dgtab, int B, int V, int h, int w, int H, int D, int ntok, float* ws, hipStream_t s) {
+  // every (head, token range) workgroup stores its partial tables in the range's slab of `ws`; the ranges are then added in
+  // a fixed order (round 4: instead of one fp32 atomic flush per workgroup -- bitwise reproducible)
+  int cpw;
+  const int splits = varagg_bwd_splits(ntok, H, &cpw);
+  float* ws_s = ws;
+  float* ws_g = ws + (size_t)splits * H * V * 5;
   const size_t shm = (size_t)VM_T * DH * 2 + 2 * (size_t)VM_T * VM_NV * 2 +
                      sizeof(float) * (size_t)(VM_T * VM_GS + VM_T * V * 4 + 2 * VM_T * V);
   static bool attr_set = false;   // one flag per instantiation
@@ -423,7 +440,9 @@ static void varagg_bwd_mfma_launch(const float* x, const float* gtab, const floa
     attr_set = true;
   }
   hipLaunchKernelGGL(varagg_bwd_mfma_kernel<DH>, dim3((unsigned)H, (unsigned)splits), dim3(256), shm, s, x, gtab, attw,
-                     (const bf16_t*)dz, dstab, dgtab, B, V, h, w, H, D, cpw);
+                     (const bf16_t*)dz, ws_s, ws_g, B, V, h, w, H, D, cpw);
+  o2_sum_parts(ws_s, splits, (int64_t)H * V * 5, dstab, (int64_t)H * V * 5, 1.0f, 1, s);     // += , as the atomics did
+  o2_sum_parts(ws_g, splits, (int64_t)V * 5 * D, dgtab, (int64_t)V * 5 * D, 1.0f, 1, s);
 }
 
 }  // namespace
@@ -448,9 +467,16 @@ extern "C" int orbit2_varagg_fwd(const float* x, const float* stab, const float*
   return O2_OK;
 }
 
+extern "C" int64_t orbit2_varagg_bwd_ws_floats(int B, int V, int h, int w, int H, int D) {
+  if (va_check(B, V, h, w, H, D)) return 0;
+  const int64_t ntok = (int64_t)B * (h / 2) * (w / 2);
+  if (ntok >= (1ll << 31) - 64) return 0;
+  return (int64_t)varagg_bwd_splits((int)ntok, H, nullptr) * ((int64_t)H * V * 5 + (int64_t)V * 5 * D);
+}
+
 extern "C" int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
-                                 float* dgtab, int B, int V, int h, int w, int H, int D, void* stream) {
-  if (!x || !gtab || !attw || !dz || !dstab || !dgtab) return O2_ERR_ARG;
+                                 float* dgtab, int B, int V, int h, int w, int H, int D, float* ws, void* stream) {
+  if (!x || !gtab || !attw || !dz || !dstab || !dgtab || !ws) return O2_ERR_ARG;
   int rc = va_check(B, V, h, w, H, D);
   if (rc) return rc;
   const int64_t ntok = (int64_t)B * (h / 2) * (w / 2);
@@ -458,9 +484,9 @@ extern "C" int orbit2_varagg_bwd(const float* x, const float* gtab, const float*
   static const bool force_scalar = getenv("ORBIT2_VARAGG_SCALAR") != nullptr;   // debugging aid: the fp32 VALU kernel
   if (!force_scalar && (dh == 64 || dh == 128 || dh == 256) && 5 * V <= VM_NV && ntok < (1ll << 31) - 64) {
     hipStream_t s = (hipStream_t)stream;
-    if (dh == 64) varagg_bwd_mfma_launch<64>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, s);
-    else if (dh == 128) varagg_bwd_mfma_launch<128>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, s);
-    else varagg_bwd_mfma_launch<256>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, s);
+    if (dh == 64) varagg_bwd_mfma_launch<64>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, ws, s);
+    else if (dh == 128) varagg_bwd_mfma_launch<128>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, ws, s);
+    else varagg_bwd_mfma_launch<256>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, ws, s);
     O2_CHECK_LAUNCH();
     return O2_OK;
   }

@@ -13,11 +13,11 @@ def test_library_exports_every_declared_symbol():
     assert os.path.exists(_hip.LIB_PATH)
     lib = ctypes.CDLL(_hip.LIB_PATH)
     hdr = open(os.path.join(ROOT, "include", "orbit2_hip.h")).read()
-    names = sorted(set(re.findall(r"\bint\s+(orbit2_\w+)\s*\(", hdr)))
+    names = sorted(set(re.findall(r"\b(?:int|int64_t)\s+(orbit2_\w+)\s*\(", hdr)))
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export " + n
-    assert lib.orbit2_abi_version() == 3
+    assert lib.orbit2_abi_version() == 4
 
 
 def test_gemm_args_struct_matches_header():

@@ -112,8 +112,8 @@ def test_fully_sharded_engine_matches_replicated_engine(golden_dir, monkeypatch)
     """SURVEY 8f-4 (reference FSDP FULL_SHARD, examples/intermediate_downscaling.py:609-617) on the GPU with the collectives
     forced on over a single-rank RCCL group: units gathered one ahead on the communication stream, gradients
     reduce-scattered from pooled buffers, AdamW on the chunks.  After ONE step the parameters of every Block and of the head
-    are bit-identical to the replicated engine's (their gradients do not pass through the atomically accumulated
-    variable-aggregation backward); three steps keep the two loss trajectories together; the full state dict round-trips."""
+    -- and, since round 4 made the conv / variable-aggregation gradient sums fixed-order, every other parameter too -- are
+    bit-identical to the replicated engine's; three steps keep the two loss trajectories together; the full state dict round-trips."""
     import torch.distributed as dist
     import torch.nn as nn
     import climate_learn as cl
@@ -153,11 +153,8 @@ def test_fully_sharded_engine_matches_replicated_engine(golden_dir, monkeypatch)
                 assert traj["rep"][0] == traj["fsdp"][0]     # same weights, same masks: the same forward
                 a, b = eng["rep"].state_dict(), f.state_dict()
                 assert set(a) == set(b)
-                for k in a:
-                    if k.startswith("blocks.") or k.startswith("head."):
-                        assert torch.equal(a[k], b[k]), k
-                    else:
-                        assert torch.allclose(a[k], b[k], rtol=0, atol=2e-3), k      # +-lr on atomically summed gradients
+                for k in a:          # EVERY parameter: no float atomics are left on any gradient path (round 4)
+                    assert torch.equal(a[k], b[k]), k
         assert all(abs(p - q) / p < 2e-3 for p, q in zip(traj["rep"], traj["fsdp"])), traj
         assert len(f._pfree) == 3 and len(f._gfree) == 2        # every pooled buffer came back
         with torch.no_grad():                                   # eval forward through the sharded engine

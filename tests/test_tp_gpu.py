@@ -190,8 +190,8 @@ def _train_worker(rank, world, port, q):
         for k in a:
             same = torch.equal(a[k], b[k])
             if tp.split_kind(k) is None:
-                # replicas stay BIT-identical: the engine overwrites their gradients with the first rank's (the conv /
-                # var-agg backward's atomic adds differ in summation order, AdamW would amplify that to +-lr)
+                # replicas stay BIT-identical with NO exchange of their gradients (round 4: the conv / var-agg backward sums
+                # are fixed-order two-stage reductions; with the fp32 atomics of rounds 2-3 they drifted within three steps)
                 assert same, (k, _rel_l2(a[k], b[k]))
             else:
                 assert not same, k
