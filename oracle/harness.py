@@ -44,6 +44,46 @@ def nerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
 
 
+TOL_FLOOR, TOL_FACTOR = 2e-2, 1.5
+
+
+def grad_tolerance(spread):
+    """the tolerance contract: a HIP result may differ from the fp32 oracle by the contract's 2e-2 (normalised max
+    error) or by 1.5 x what running the SAME math in plain bf16 moves that tensor, whichever is larger.  `spread` is that
+    measured bf16-vs-fp32 figure: the reference's own (tests/golden/bf16_spread.npz, written from the reference's modules by
+    tests/golden/make_golden_bf16_spread.py) where a fixture exists, the oracle's (oracle_bf16_spread) elsewhere."""
+    return max(TOL_FLOOR, TOL_FACTOR * float(spread))
+
+
+def oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, loss="bayesian_tv", vw=None, fp32_grads=None, **kw):
+    """the yardstick where no reference fixture exists for the configuration: the oracle (pinned to the reference by
+    tests/test_oracle_golden.py) run once more with weights, inputs and arithmetic in plain bf16; returns
+    {name: normalised max error of its bf16 gradient against its fp32 gradient}, and the same for rel. L2 under 'l2.'+name"""
+    def cast(o, dt):
+        if torch.is_tensor(o):
+            return o.to(dt) if o.is_floating_point() else o
+        if isinstance(o, dict):
+            return {k: cast(v, dt) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(cast(v, dt) for v in o)
+        return o
+
+    def run(dt):
+        s = {k: v.clone().to(dt).requires_grad_() for k, v in sd.items()}
+        yy = y.to(dt) if loss.startswith("perceptual") else y       # (the LPIPS network takes the target as an input image)
+        l = O.training_loss(s, cfg, x.to(dt), yy, in_vars, out_vars, loss, vw, **cast(kw, dt))
+        l.float().backward()
+        return {k: v.grad.detach().float() for k, v in s.items() if v.grad is not None}
+    g32 = fp32_grads if fp32_grads is not None else run(torch.float32)
+    g16 = run(torch.bfloat16)
+    out = {}
+    for k, g in g32.items():
+        if k in g16:
+            out[k] = nerr(g16[k], g)
+            out["l2." + k] = float((g16[k].double() - g.double()).norm() / g.double().norm().clamp_min(1e-30))
+    return out
+
+
 def smoke_step():
     from climate_learn import _hip
     from climate_learn.metrics import Bayesian_TV
@@ -63,6 +103,11 @@ def smoke_step():
     e_loss = abs(float(loss) - float(ref)) / abs(float(ref))
     e_g = nerr(model.head[0].weight.grad, sdo["head.0.weight"].grad)
     e_q = nerr(model.blocks[0].attn.qkv.weight.grad, sdo["blocks.0.attn.qkv.weight"].grad)
-    print("[smoke] loss hip=%.6f oracle=%.6f rel=%.2e | grad err head.0=%.2e qkv=%.2e" %
-          (float(loss), float(ref), e_loss, e_g, e_q), flush=True)
-    assert e_loss < 2e-2 and e_g < 5e-2 and e_q < 5e-2, "HIP step disagrees with the CPU oracle"
+    # tolerance per tensor: 2e-2, or 1.5 x what plain bf16 arithmetic moves this tensor of this very model (measured here)
+    sp = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw,
+                            fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
+    t_g, t_q = grad_tolerance(sp["head.0.weight"]), grad_tolerance(sp["blocks.0.attn.qkv.weight"])
+    print("[smoke] loss hip=%.6f oracle=%.6f rel=%.2e | grad err head.0=%.2e (bf16 spread %.2e, tol %.2e) qkv=%.2e "
+          "(bf16 spread %.2e, tol %.2e)" % (float(loss), float(ref), e_loss, e_g, sp["head.0.weight"], t_g, e_q,
+                                            sp["blocks.0.attn.qkv.weight"], t_q), flush=True)
+    assert e_loss < 2e-2 and e_g <= t_g and e_q <= t_q, "HIP step disagrees with the CPU oracle"

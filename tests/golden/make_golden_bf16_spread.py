@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""How far the REFERENCE model moves when it runs in bf16 instead of fp32 -- the yardstick of the GPU tolerance contract
+("bf16 <= 2e-2 vs the fp32 oracle", measured there as out 4.5e-3 / grads 1.0-1.5e-2 on interm_8m).
+
+For every whole-model fixture the GPU tests use (model_*_hd64.npz, written by make_golden.py from the reference's own modules),
+the reference `Res_Slim_ViT` is rebuilt with the fixture's weights and run twice on the CPU, eval mode: fp32 (FusedAttn.NONE) and
+`model.bfloat16()` on bf16 inputs (FusedAttn.DEFAULT = scaled_dot_product_attention, the reference's bf16 CPU-runnable path);
+loss = bayesian_tv of the training step (clamped precipitation, cropped target) computed in fp32 from the prediction.  Stored
+per case: normalised max error (max |a - b| / max |b|) and relative L2 error of the prediction and of every parameter gradient,
+bf16 run against fp32 run -> tests/golden/bf16_spread.npz.  tests/test_model_gpu.py / test_configs_gpu.py / oracle/harness.py
+hold the HIP path to max(2e-2, 1.5 x this spread) per tensor.
+
+Runs ONLY in the build container (where /root/reference exists); numbers only are stored.
+Usage:  python tests/golden/make_golden_bf16_spread.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (the shim recipe of SURVEY 8c lives there)
+
+CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+CASES = {     # = the *_hd64 cases of make_golden.py
+    "v5c1_hd64": dict(in_vars=CONST + ["total_precipitation_24hr"], out_vars=["total_precipitation_24hr"],
+                      grid=(16, 32), run_grid=(16, 32), D=128, depth=2, heads=2, dd=1),
+    "v7c3_hd64": dict(in_vars=["2m_temperature_max", "lattitude", "total_precipitation_24hr", "orography",
+                               "landcover", "land_sea_mask", "2m_temperature_min"],
+                      out_vars=["2m_temperature_min", "total_precipitation_24hr", "2m_temperature_max"],
+                      default_vars=CONST + ["2m_temperature", "total_precipitation_24hr", "2m_temperature_min",
+                                            "2m_temperature_max"],
+                      grid=(16, 32), run_grid=(16, 32), D=128, depth=1, heads=2, dd=2),
+    "v6c2_regrid_hd64": dict(in_vars=["2m_temperature", "lattitude", "orography", "landcover", "land_sea_mask",
+                                      "total_precipitation_24hr"],
+                             out_vars=["total_precipitation_24hr", "2m_temperature"],
+                             default_vars=CONST + ["2m_temperature", "10m_u_component_of_wind",
+                                                   "total_precipitation_24hr"],
+                             grid=(8, 16), run_grid=(16, 32), D=128, depth=1, heads=2, dd=1),
+}
+VW = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0, "2m_temperature": 10.0}
+
+
+def nerr(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def main():
+    mg.install_shims()
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29431")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    rs = importlib.import_module("climate_learn.models.hub.res_slimvit")
+    fn = importlib.import_module("climate_learn.metrics.functional")
+    FusedAttn = importlib.import_module("climate_learn.utils.fused_attn").FusedAttn
+    torch.set_num_threads(4)
+    out = {}
+    for tag, c in CASES.items():
+        z = np.load(os.path.join(HERE, "model_%s.npz" % tag))
+        dv = c.get("default_vars", c["in_vars"])
+        Vn, C = len(c["in_vars"]), len(c["out_vars"])
+        x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+        pi = c["out_vars"].index("total_precipitation_24hr")
+        res = {}
+        for mode in ("fp32", "bf16"):
+            torch.manual_seed(0)
+            model = rs.Res_Slim_ViT(dv, c["grid"], Vn, C, history=1, superres_mag=4, cnn_ratio=4, patch_size=2, drop_path=0.1,
+                                    drop_rate=0.1, learn_pos_emb=True, embed_dim=c["D"], depth=c["depth"], decoder_depth=c["dd"],
+                                    num_heads=c["heads"], mlp_ratio=4,
+                                    FusedAttn_option=FusedAttn.NONE if mode == "fp32" else FusedAttn.DEFAULT)
+            model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}, strict=True)
+            model.data_config(156.0, c["run_grid"], Vn, C)
+            model.eval()
+            xin = x
+            if mode == "bf16":
+                model = model.bfloat16()
+                xin = x.bfloat16()
+            pred = model(xin, c["in_vars"], c["out_vars"]).float()
+            yhat = pred.clone()
+            yhat[:, pi] = torch.clamp(pred[:, pi], min=0.0)
+            yc = y[:, :, : yhat.shape[2], : yhat.shape[3]]
+            loss = fn.bayesian_tv(yhat, yc, c["out_vars"], VW, False)[-1]
+            loss.backward()
+            res[mode] = (pred.detach(), float(loss), {n: p.grad.detach().float() for n, p in model.named_parameters() if p.grad is not None})
+        # the fp32 run must be the fixture's (same weights, same inputs): the spread is measured against pinned numbers
+        assert nerr(res["fp32"][0], torch.from_numpy(z["pred"])) < 1e-5, tag
+        out["%s/pred" % tag] = np.float64(nerr(res["bf16"][0], res["fp32"][0]))
+        out["%s/loss" % tag] = np.float64(abs(res["bf16"][1] - res["fp32"][1]) / abs(res["fp32"][1]))
+        for n, g32 in res["fp32"][2].items():
+            assert nerr(g32, torch.from_numpy(z["g.bayesian_tv." + n])) < 1e-4, (tag, n)
+            out["%s/g.%s" % (tag, n)] = np.float64(nerr(res["bf16"][2][n], g32))
+            out["%s/l2.%s" % (tag, n)] = np.float64(rel_l2(res["bf16"][2][n], g32))
+        gs = sorted(((v, k) for k, v in out.items() if k.startswith(tag + "/g.")), reverse=True)
+        print("%s: pred %.2e loss %.2e | gradients: median %.2e, worst %s" %
+              (tag, out[tag + "/pred"], out[tag + "/loss"], float(np.median([v for v, _ in gs])),
+               ", ".join("%s %.2e" % (k.split("/g.")[1], v) for v, k in gs[:6])), flush=True)
+    np.savez_compressed(os.path.join(HERE, "bf16_spread.npz"), **out)
+    print("wrote bf16_spread.npz with %d entries" % len(out))
+
+
+if __name__ == "__main__":
+    main()

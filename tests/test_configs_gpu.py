@@ -35,8 +35,9 @@ def rel_l2(a, b):
 
 def test_interm_117m_whole_model_forward_backward_vs_oracle():
     """BASELINE configs[1] at its real architecture and grid (2 of the 8 samples of the YAML batch: the oracle runs them
-    on the CPU in seconds): prediction <= 2e-2, loss <= 1e-2, every parameter gradient <= 5e-2 (normalised max) or <= 2e-2
-    relative L2 -- the tolerances of the reference-golden whole-model test"""
+    on the CPU in seconds): prediction <= 2e-2, loss <= 1e-2, every parameter gradient within max(2e-2, 1.5 x the bf16 spread of
+    that tensor) in normalised max error AND relative L2 -- the spread measured here by running the oracle once more in plain
+    bf16 on the same weights and inputs (oracle/harness.py: no reference fixture exists at this size)"""
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.trainer import training_step
     from oracle.harness import build_pair
@@ -64,10 +65,13 @@ def test_interm_117m_whole_model_forward_backward_vs_oracle():
             continue
         assert p.grad is not None, name
         worst[name], l2[name] = nerr(p.grad, g), rel_l2(p.grad, g)
-    print(sorted(((round(e, 4), round(l2[k], 4), k) for k, e in worst.items()), reverse=True)[:10])
-    bad = {k: (e, l2[k]) for k, e in worst.items() if e > 5e-2 and l2[k] > 2e-2}
+    from oracle.harness import grad_tolerance, oracle_bf16_spread
+    sp = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", VW,
+                            fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
+    print(sorted(((round(e, 4), round(sp[k], 4), k) for k, e in worst.items()), reverse=True)[:10])
+    bad = {k: (e, sp[k], l2[k], sp["l2." + k]) for k, e in worst.items()
+           if e > grad_tolerance(sp[k]) or l2[k] > grad_tolerance(sp["l2." + k])}
     assert len(worst) > 120 and not bad, bad
-    assert max(l2.values()) < 6e-2, max(l2.items(), key=lambda kv: kv[1])
 
 
 def test_interm_10b_training_step_with_recompute():
@@ -203,7 +207,7 @@ def test_interm_1b_daymet_like_hybrid_perceptual_step(monkeypatch):
     assert float(l2) == float(l1)
     assert torch.equal(model.blocks[7].attn.qkv.weight._o2g, g1) and torch.equal(model.head[8].weight._o2g, gh)
     l3 = one()                                               # fresh dropout / DropPath masks: a different step
-    assert abs(float(l3) - float(l1)) > 1e-5 * abs(float(l1)) and rel_l2(model.blocks[7].attn.qkv.weight._o2g, g1) > 5e-2
+    assert abs(float(l3) - float(l1)) > 1e-5 * abs(float(l1)) and rel_l2(model.blocks[7].attn.qkv.weight._o2g, g1) > 0.05
     scaler.step(opt)
     assert scaler.update() is False
     # the loss object on the step's own predictions against the oracle (CPU, fp32): L1 + 0.5 LPIPS + lat-weighted MSE

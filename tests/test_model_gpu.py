@@ -1,7 +1,11 @@
 """Whole-model GPU parity: the HIP Res_Slim_ViT against (a) golden vectors produced by the reference's own
 modules (tests/golden/model_*_hd64.npz) and (b) the CPU oracle on seeded inputs.  Tolerances: bf16 compute vs
-the fp32 reference, normalised max error (max|a-b|/max|b|): prediction <= 2e-2, gradients <= 5e-2 (SURVEY 7:
-the reference's own bf16-vs-fp32 spread is 4.5e-3 / 1.5e-2), loss <= 1e-2 relative."""
+the fp32 reference, normalised max error (max|a-b|/max|b|): prediction <= 2e-2, loss <= 1e-2 relative, every gradient tensor
+<= max(2e-2, 1.5 x the REFERENCE's own bf16-vs-fp32 spread of that tensor) -- tests/golden/bf16_spread.npz, measured by running
+the reference model in bf16 on the fixture's weights and inputs (tests/golden/make_golden_bf16_spread.py); oracle/harness.py:
+grad_tolerance.  Tensors whose tolerance is above 2e-2 are therefore exactly those the reference itself moves by more than
+1.3e-2 in bf16 (pos_embed 8.4e-2, token_embeds.* up to 4.5e-2, path2.0.weight 2.8e-2, norm1 2.1-2.7e-2: per-token or
+few-token sums that carry the rounding noise of the residual-gradient stream un-averaged)."""
 import os
 
 import numpy as np
@@ -82,13 +86,16 @@ def test_forward_loss_grads_vs_reference_golden(golden_dir, tag):
         if k in z.files:
             assert p.grad is not None, n
             worst[n] = nerr(p.grad, z[k])
-    # per-token gradients that are NOT summed over many tokens (pos_embed: batch sum only) carry the bf16
-    # rounding noise of the residual-gradient stream un-averaged; they are judged by relative L2 error.
+    # the contract: per tensor, 2e-2 or 1.5 x the reference's own bf16-vs-fp32 spread of THAT tensor on these weights / inputs
+    from oracle.harness import grad_tolerance
+    sp = np.load(os.path.join(golden_dir, "bf16_spread.npz"))
     l2 = {n: rel_l2(p.grad, z["g.bayesian_tv." + n]) for n, p in m.named_parameters() if n in worst}
-    print(sorted(((round(e, 4), round(l2[n], 4), n) for n, e in worst.items()), reverse=True)[:12])
-    bad = {n: (e, l2[n]) for n, e in worst.items() if e > 5e-2 and l2[n] > 2e-2}
+    tol = {n: grad_tolerance(sp["%s/g.%s" % (tag, n)]) for n in worst}
+    tol2 = {n: grad_tolerance(sp["%s/l2.%s" % (tag, n)]) for n in worst}
+    print(sorted(((round(e, 4), round(float(sp["%s/g.%s" % (tag, n)]), 4), n) for n, e in worst.items()), reverse=True)[:12])
+    bad = {n: (e, tol[n], l2[n], tol2[n]) for n, e in worst.items() if e > tol[n] or l2[n] > tol2[n]}
     assert len(worst) > 25 and not bad, bad
-    assert max(l2.values()) < 5e-2, l2
+    assert nerr(pred, z["pred"]) <= grad_tolerance(sp[tag + "/pred"])
 
 
 @pytest.mark.parametrize("tag", ["v5c1_hd64"])
@@ -357,17 +364,18 @@ def test_train_mode_step_matches_oracle_with_replicated_masks(p_drop):
     ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw, masks=masks)
     ref.backward()
     assert abs(float(loss) - float(ref)) / abs(float(ref)) < 2e-2
+    # yardstick: the same masked step of the oracle in plain bf16 (no reference fixture exists for train mode: its RNG streams
+    # cannot be reproduced); tolerance per tensor = max(2e-2, 1.5 x that spread)
+    from oracle.harness import grad_tolerance, oracle_bf16_spread
+    spread = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw, masks=masks,
+                                fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
     for name, p in (("head.0.weight", model.head[0].weight), ("blocks.2.mlp.fc2.weight", model.blocks[2].mlp.fc2.weight),
                     ("blocks.1.attn.qkv.weight", model.blocks[1].attn.qkv.weight),
                     ("blocks.0.attn.proj.weight", model.blocks[0].attn.proj.weight),
                     ("blocks.0.norm1.weight", model.blocks[0].norm1.weight), ("var_agg.proj.weight", model.var_agg.proj.weight),
                     ("var_agg.kv.weight", model.var_agg.kv.weight), ("pos_embed", model.pos_embed)):
         g = p.grad if p.grad is not None else p._o2g.float()
-        tol = 6e-2
-        if name == "pos_embed":
-            assert float((g.float().cpu() - sdo[name].grad).norm() / sdo[name].grad.norm()) < tol, name
-        else:
-            assert nerr(g, sdo[name].grad) < tol, name
+        assert nerr(g, sdo[name].grad) <= grad_tolerance(spread[name]), (name, nerr(g, sdo[name].grad), spread[name])
     # sanity: the masks matter for what was just compared -- eval-mode gradients are far outside the tolerance
     sde = {k: v.clone().requires_grad_() for k, v in sd.items()}
     O.training_loss(sde, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw).backward()
@@ -430,9 +438,12 @@ def test_daymet_like_three_outputs_perceptual_loss():
     ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "perceptual", lpips_sd=lp)
     ref.backward()
     assert abs(float(loss) - float(ref)) / abs(float(ref)) < 1e-2
+    from oracle.harness import grad_tolerance, oracle_bf16_spread
+    spread = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "perceptual", lpips_sd=lp,
+                                fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
     for name, p in (("head.0.weight", model.head[0].weight), ("blocks.0.mlp.fc1.weight", model.blocks[0].mlp.fc1.weight),
                     ("blocks.0.attn.qkv.weight", model.blocks[0].attn.qkv.weight), ("conv_out.weight", model.conv_out.weight)):
-        assert nerr(p.grad, sdo[name].grad) < 6e-2, name
+        assert nerr(p.grad, sdo[name].grad) <= grad_tolerance(spread[name]), (name, nerr(p.grad, sdo[name].grad), spread[name])
 
 
 def test_odd_token_count_grid_trains():
@@ -452,10 +463,13 @@ def test_odd_token_count_grid_trains():
     ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw)
     ref.backward()
     assert abs(float(loss) - float(ref)) / abs(float(ref)) < 2e-2
+    from oracle.harness import grad_tolerance, oracle_bf16_spread
+    spread = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw,
+                                fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
     for name, p in (("head.0.weight", model.head[0].weight), ("blocks.1.mlp.fc2.weight", model.blocks[1].mlp.fc2.weight),
                     ("blocks.0.attn.qkv.weight", model.blocks[0].attn.qkv.weight),
                     ("blocks.0.attn.proj.bias", model.blocks[0].attn.proj.bias), ("blocks.1.norm1.weight", model.blocks[1].norm1.weight)):
-        assert nerr(p.grad, sdo[name].grad) < 6e-2, name
+        assert nerr(p.grad, sdo[name].grad) <= grad_tolerance(spread[name]), (name, nerr(p.grad, sdo[name].grad), spread[name])
 
 
 def test_smoke_entry():
