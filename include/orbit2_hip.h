@@ -112,8 +112,9 @@ int orbit2_attn_bwd(const void* qkv, const void* out, const void* dout, const fl
  * (relative 2^-9 per element of that operand: harmless at ordinary score magnitudes, ~1e-2 of the output when scores reach
  * tens of nats).  dqkv is in both cases the gradient with respect to the UNSCALED q, k, v. */
 #define ORBIT2_ATTN_Q_PRESCALED 4
-/* Forward at d = 128 with ORBIT2_ATTN_Q_PRESCALED and L a multiple of 256 (<= 16384) runs the generated one-wave-per-SIMD kernel
- * (csrc/attn_fwd_asm.h, tools/gen_attn_fwd.py); this flag keeps the compiler-scheduled kernels instead (A/B timing, tests). */
+/* Forward and the dQ pass of the backward at d = 128 with ORBIT2_ATTN_Q_PRESCALED and L a multiple of 256 (<= 16384) run the
+ * generated one-wave-per-SIMD kernels (csrc/attn_fwd_asm.h, attn_dq_asm.h; tools/gen_attn_fwd.py, gen_attn_dq.py); this flag
+ * keeps the compiler-scheduled kernels instead (A/B timing, tests). */
 #define ORBIT2_ATTN_NO_W4 8
 int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
                        uint64_t seed, int flags, void* stream);

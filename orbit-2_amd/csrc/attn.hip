@@ -20,6 +20,7 @@
 #endif
 #include "../../include/orbit2_hip.h"
 #include "attn_fwd_asm.h"
+#include "attn_dq_asm.h"
 
 namespace {
 
@@ -736,6 +737,57 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
       w[1] = pack_bf2(dq[db][4 * g4 + 2] * fs, dq[db][4 * g4 + 3] * fs);
       *reinterpret_cast<u32x2*>(drow + dd) = w;
     }
+}
+
+// =============================================================================================
+// backward, dQ, d = 128, q stored pre-scaled, L % 256 == 0: the GENERATED kernel (tools/gen_attn_dq.py -> attn_dq_asm.h)
+// =============================================================================================
+// Same construction as attn_fwd_w4_kernel (one wave per SIMD, two 32-row blocks per wave, every instruction placed by the
+// generator, the same text executed on the CPU by tests/test_attn_dq_asm_emu_cpu.py); the schedule is described in the
+// generator's header.  The compiler contributes the coordinates, the key-group hash table and the lane's two row hashes.
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ nlse2, const float* __restrict__ ndelta,
+                                                               bf16_t* __restrict__ dqkv, int L, int H, unsigned thr, float fs,
+                                                               uint64_t seed_arg, int Lp) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(1024))) char smem[O2_DQ_LDS_BYTES(O2_AF_MAX_L)];   // 4 x [K 16 KiB] | 4 x [V 16 KiB] | key-group hashes
+  const uint64_t seed = seed_arg ^ o2_seed_salt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_i, head, b;
+  attn_tile_coords(L / 256, H, tile_i, head, b);
+  const int q0 = tile_i * 256 + wave * 64;
+  const size_t tstride = (size_t)3 * H * D;
+  if (DROP) {
+    uint32_t* skh = reinterpret_cast<uint32_t*>(smem + O2_DQ_KH_OFF);
+    for (int i = tid; i < L / 4 + 16; i += 256) {
+      const uint32_t T = (uint32_t)i >> 4, wq = (uint32_t)i & 15;
+      skh[i] = o2_attn_keyhash(seed, T * 16 + 2 * (wq & 7) + (wq >> 3));
+    }
+  }
+  __syncthreads();
+  const char* kptr = reinterpret_cast<const char*>(qkv + (size_t)b * L * tstride + (size_t)H * D + (size_t)head * D);
+  const char* qptr = reinterpret_cast<const char*>(qkv + ((size_t)b * L + q0) * tstride + (size_t)head * D);
+  const char* doptr = reinterpret_cast<const char*>(dout + (((size_t)b * L + q0) * H + head) * D);
+  char* optr = reinterpret_cast<char*>(dqkv + ((size_t)b * L + q0) * tstride + (size_t)head * D);
+  const char* lseptr = reinterpret_cast<const char*>(nlse2 + ((size_t)(b * H + head)) * Lp + q0);
+  const char* dltptr = reinterpret_cast<const char*>(ndelta + ((size_t)(b * H + head)) * Lp + q0);
+  const uint64_t row = (uint64_t)(b * H + head) * L + (uint64_t)(q0 + (lane & 31));
+  const uint32_t rhx = DROP ? o2_attn_rowhash(seed, row) : 0u, rhy = DROP ? o2_attn_rowhash(seed, row + 32) : 0u;
+  const uint32_t ldsb = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const int nt = L / 64, strideb = (int)(tstride * 2), hd2 = H * D * 2;
+  const uint32_t fsb = __float_as_uint(fs);
+#define O2_DQ_OPERANDS                                                                                                          \
+  [kptr] "s"(kptr), [qptr] "s"(qptr), [optr] "s"(optr), [doptr] "s"(doptr), [lseptr] "s"(lseptr), [dltptr] "s"(dltptr),        \
+      [nt] "s"(nt), [strideb] "s"(strideb), [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [fs] "s"(fsb), \
+      [dorowb] "s"(hd2), [rhx] "v"(rhx), [rhy] "v"(rhy)
+  if constexpr (DROP) {
+    asm volatile(O2_DQ_ASM_DROP : : O2_DQ_OPERANDS : O2_DQ_CLOBBERS);
+  } else {
+    asm volatile(O2_DQ_ASM_NODROP : : O2_DQ_OPERANDS : O2_DQ_CLOBBERS);
+  }
+#undef O2_DQ_OPERANDS
 }
 
 // =============================================================================================
@@ -1530,8 +1582,14 @@ static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, co
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
   const bool pre = (flags & ORBIT2_ATTN_Q_PRESCALED) != 0;
   const float opmul = pre ? 1.0f : scale * 1.4426950408889634f, kgrad = pre ? 0.6931471805599453f : scale;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                     seed, opmul, Lp);
+  if (DV == 128 && pre && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L) {
+    // the generated one-wave-per-SIMD dQ kernel (256-row workgroups whatever NW is)
+    hipLaunchKernelGGL((attn_bwd_dq_w4_kernel<DR>), dim3((unsigned)((L / 256) * H * B)), dim3(256), 0, s, q_, do_, lse, delta, dq_,
+                       L, H, thr, DR ? scale * dscale : scale, seed, Lp);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
+                       seed, opmul, Lp);
+  }
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
                        dscale, seed, opmul, kgrad, Lp);

@@ -27,6 +27,22 @@ def t(f, n=5):
 
 
 fl = 4.0 * B * H * L * L * d
+do = torch.randn(B, L, H * d, device="cuda").to(torch.bfloat16)
+for p in (0.1, 0.0):
+    o_, l_ = _hip.attn_fwd(qkv, B, L, H, d, p, 7, flags=PRE)
+    g_new = _hip.attn_bwd(qkv, o_, do, l_, B, L, H, d, p, 7, flags=PRE)
+    g_old = _hip.attn_bwd(qkv, o_, do, l_, B, L, H, d, p, 7, flags=PRE | _hip.ATTN_NO_W4)
+    torch.cuda.synchronize()
+    gq_n, gq_o = g_new.view(B, L, 3, H * d)[:, :, 0].float(), g_old.view(B, L, 3, H * d)[:, :, 0].float()
+    print("p=%.1f  bwd: max |dq_w4 - dq_old| / max|dq| = %.3e; dk/dv identical: %s" %
+          (p, float((gq_n - gq_o).abs().max() / gq_o.abs().max()), bool(torch.equal(g_new.view(B, L, 3, H * d)[:, :, 1:], g_old.view(B, L, 3, H * d)[:, :, 1:]))), flush=True)
+    rb = {"w4": [], "old": []}
+    for r in range(R):
+        rb["w4"].append(t(lambda: _hip.attn_bwd(qkv, o_, do, l_, B, L, H, d, p, 7, flags=PRE)))
+        rb["old"].append(t(lambda: _hip.attn_bwd(qkv, o_, do, l_, B, L, H, d, p, 7, flags=PRE | _hip.ATTN_NO_W4)))
+    for k in ("old", "w4"):
+        v = sorted(rb[k])
+        print("p=%.1f B=%d  bwd %-4s median %7.3f ms (min %7.3f)  %6.0f TFLOP/s algorithmic" % (p, B, k, v[len(v) // 2], v[0], 2 * fl / v[len(v) // 2] / 1e9), flush=True)
 for p in (0.1, 0.0):
     o_new, l_new = _hip.attn_fwd(qkv, B, L, H, d, p, 7, flags=PRE)
     o_old, l_old = _hip.attn_fwd(qkv, B, L, H, d, p, 7, flags=PRE | _hip.ATTN_NO_W4)

@@ -269,14 +269,18 @@ class Emu:
                     if st["wave"] != w.wid and not (w.epoch > st["retired_epoch"]):
                         raise EmuError("wave %d: LDS read of KiB %d without a barrier after wave %d's vmcnt wait: %s"
                                        % (w.wid, kb, st["wave"], self.cur))
-                self.wg.readers[kb][w.wid] = ("pending", w.epoch)
+                rd = self.wg.readers[kb].setdefault(w.wid, dict(pending=0, epoch=-1))
+                rd["pending"] += 1
+                self._cur_kbs.append(kb)
         return out
 
-    def _retire_lds_reads(self, w):
-        """the wave's LDS reads have returned (lgkmcnt(0))"""
-        for kb, rd in enumerate(self.wg.readers):
-            if w.wid in rd and rd[w.wid][0] == "pending":
-                rd[w.wid] = ("done", w.epoch)
+    def _retire_lds_read(self, w, op):
+        """an LDS read of the wave has returned (its s_waitcnt lgkmcnt retired it)"""
+        for kb in op.get("kbs", ()):
+            rd = self.wg.readers[kb].get(w.wid)
+            if rd is not None:
+                rd["pending"] -= 1
+                rd["epoch"] = w.epoch
 
     def _dma_write(self, w, lds_base, src_addr):
         lds = self.wg.lds
@@ -294,16 +298,15 @@ class Emu:
             kbs.add(d >> 10)
         if self.strict:
             for kb in kbs:
-                for wid, (state, ep) in self.wg.readers[kb].items():
-                    other = self.wg.waves[wid]
+                for wid, rd in self.wg.readers[kb].items():
                     if wid == w.wid:
-                        if state == "pending":
+                        if rd["pending"]:
                             raise EmuError("wave %d: LDS-DMA into KiB %d over its own un-waited read: %s" % (w.wid, kb, self.cur))
                     else:
                         # the reader must have finished the read before a barrier this wave has passed since
-                        if state == "pending" or not (w.epoch > ep):
-                            raise EmuError("wave %d: LDS-DMA into KiB %d that wave %d read in epoch %d (%s) with no barrier since: %s"
-                                           % (w.wid, kb, wid, ep, state, self.cur))
+                        if rd["pending"] or not (w.epoch > rd["epoch"]):
+                            raise EmuError("wave %d: LDS-DMA into KiB %d that wave %d read in epoch %d (pending %d) with no barrier since: %s"
+                                           % (w.wid, kb, wid, rd["epoch"], rd["pending"], self.cur))
                 self.wg.readers[kb] = {}
                 self.wg.dma_state[kb] = dict(wave=w.wid, retired_epoch=None, ids=None)
         return kbs
@@ -341,6 +344,7 @@ class Emu:
         op, ops, mods, text = prog[w.pc]
         self.cur = text
         self._cur_regs = []
+        self._cur_kbs = []
         w.pc += 1
         w.counts[op] = w.counts.get(op, 0) + 1
         h = getattr(self, "op_" + op, None)
@@ -474,9 +478,10 @@ class Emu:
             else:
                 if n > 15:
                     raise EmuError("lgkmcnt above 15")
-                w.lgkm = w.lgkm[max(0, len(w.lgkm) - n):] if n > 0 else []
-                if n == 0:
-                    self._retire_lds_reads(w)
+                keep = w.lgkm[max(0, len(w.lgkm) - n):] if n > 0 else []
+                for op in w.lgkm[:len(w.lgkm) - len(keep)]:
+                    self._retire_lds_read(w, op)
+                w.lgkm = keep
 
     # ---- vector ALU ---------------------------------------------------------------------------------------------------------
     def _regs(self, toks):
@@ -695,7 +700,7 @@ class Emu:
         for k in range(4):
             file[idx + k] = data[:, k]
             w.wtime[(kind, idx + k)] = (w.issue, "lds")
-        w.lgkm.append(dict(regs={(kind, idx + k) for k in range(4)}))
+        w.lgkm.append(dict(regs={(kind, idx + k) for k in range(4)}, kbs=list(self._cur_kbs)))
 
     def op_ds_read_b64_tr_b16(self, w, ops, mods):
         if w.exec != (1 << 64) - 1:
@@ -717,7 +722,7 @@ class Emu:
         file[idx + 1] = out[:, 2].astype(np.uint32) | (out[:, 3].astype(np.uint32) << 16)
         for k in range(2):
             w.wtime[(kind, idx + k)] = (w.issue, "lds")
-        w.lgkm.append(dict(regs={(kind, idx + k) for k in range(2)}))
+        w.lgkm.append(dict(regs={(kind, idx + k) for k in range(2)}, kbs=list(self._cur_kbs)))
 
     def op_ds_write_b64(self, w, ops, mods):
         addr = self._lds_addr(w, ops[0], mods)
@@ -774,6 +779,19 @@ class Emu:
             for k in range(4):
                 file[idx + k][l] = d[k]
         w.vm.append(dict(regs={(kind, idx + k) for k in range(4)}))
+
+    def op_global_load_dword(self, w, ops, mods):
+        kind, idx, n = parse_reg(ops[0])
+        voff = self._src(w, ops[1]).astype(np.int64)
+        src = self._sval(w, ops[2]) + voff + int(mods.get("offset", 0))
+        file = w.v if kind == "v" else w.a
+        self._touch(w, (kind, idx), read=False)
+        for l in range(64):
+            a = int(src[l])
+            if a < 0 or a + 4 > self.wg.mem.size:
+                raise EmuError("global load out of range: " + self.cur)
+            file[idx][l] = self.wg.mem[a:a + 4].view(np.uint32)[0]
+        w.vm.append(dict(regs={(kind, idx)}))
 
     def _gstore(self, w, ops, mods, ndw):
         voff = self._src(w, ops[0]).astype(np.int64)
