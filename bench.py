@@ -42,7 +42,7 @@ MODELS = {  # configs/interm_*.yaml of the reference
 }
 PEAK_BF16 = 2.5e15   # dense MFMA peak, MI355X_MICROARCH.md
 MALL_JSON = "r03_mall_latency.json"  # Infinity-Cache share of that traffic (TCC_EA0_RDREQ_LEVEL pass of tools/mall_probe.py)
-TRAFFIC_JSON = "r03_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
+TRAFFIC_JSON = "r04_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
 METRIC = "climate-grid samples/sec/node (fwd+bwd), interm_1b ERA5 1.4°→0.25°, 1/2/4/8 GPUs"
 
 
