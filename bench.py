@@ -57,6 +57,9 @@ def parse():
                     help="per-GPU batch: 16 (1 / 2 / 4 / 8 / 16 / 32 all fit one GPU; 8 is 1 % slower, 32 = the reference "
                          "YAML's batch_size gives the same rate at twice the step time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-comm-stats", action="store_true",
+                    help="do not attach CommStats (timing events + collective waits on the communication stream) to the engine: "
+                         "A/B of what the accounting itself costs (tools/forced_collectives_ab.sh)")
     ap.add_argument("--eager-baseline", type=int, default=0, metavar="B",
                     help="also time the oracle (the plain-PyTorch restatement of the reference) ON THE GPU under bf16 autocast "
                          "with the framework's fused attention, per-GPU batch B: what the reference's eager PyTorch step costs "
@@ -410,7 +413,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
-    if (world > 1 or force) and not a.graph:
+    if (world > 1 or force) and not a.graph and not a.no_comm_stats:
         eng.comm_stats = cl.CommStats()                 # HIP-event accounting of the collectives over the timed region
     if a.graph:
         # instrumented eager pass for the per-kernel (roofline) numbers, then the captured step for the throughput

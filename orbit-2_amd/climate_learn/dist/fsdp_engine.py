@@ -53,6 +53,18 @@ class _Unit(Bucket):
 
 
 class HipFullyShardedDataParallel(nn.Module):
+
+    # communication accounting (CommStats) records timing-enabled events and reads them back: not inside a hipGraph capture
+    @property
+    def comm_stats(self):
+        return self.__dict__.get("_comm_stats")
+
+    @comm_stats.setter
+    def comm_stats(self, v):
+        if v is not None and self.__dict__.get("_o2_capture_live", False):
+            raise RuntimeError("comm_stats cannot be switched on while a hipGraph capture of this engine's step exists "
+                               "(GraphedTrainStep): captured events carry no timestamps")
+        self.__dict__["_comm_stats"] = v
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (), is_lowp=None,
                  sync_module_states: bool = True, replicate_group=None, prefetch: bool = True, pool_size: int = 3,
                  tp_group=None):

@@ -52,6 +52,13 @@ class GraphedTrainStep:
 
     def capture(self):
         from . import _ops
+        # CommStats records timing-enabled events on the capturing streams and reads them back with elapsed_time: a captured event
+        # has no timestamp (querying it is invalid), and round 3's segfault in hipStreamEndCapture happened with exactly this
+        # combination on the path -- refuse it instead of handing it to the runtime
+        if getattr(self.engine, "comm_stats", None) is not None and not getattr(self, "_allow_comm_stats", False):
+            raise RuntimeError("GraphedTrainStep: engine.comm_stats is set -- communication accounting uses timing events and "
+                               "cannot run inside a hipGraph capture; unset it (or run the step eagerly)")
+        self.engine._o2_capture_live = True
         self.scale = float(self.scaler.get_scale()) if self.scaler is not None else 1.0
         self._seed_mark = _ops.seeds.mark()
         side = torch.cuda.Stream(device=self.device)
