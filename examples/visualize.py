@@ -57,7 +57,7 @@ def main():
     variable = "total_precipitation_24hr" if "total_precipitation_24hr" in out_vars else out_vars[0]
     res = visualize_at_index(model, dm_vis, dm_vis, out_list=out_vars, in_transform=denorm, out_transform=denorm,
                              variable=variable, src=data_key, device=device, div=div, overlap=overlap, index=0)
-    print("stitched", {k: v.shape for k, v in res.items()}, flush=True)
+    print("stitched", {k: (v.shape if hasattr(v, "shape") else v) for k, v in res.items()}, flush=True)
     x, y, iv, ov = next(iter(dm_vis.test_dataloader()))[:4]
     x, y = x.to(device), y.to(device)
     pred = denorm(tiled_predict(model, x, y, iv, ov, div, overlap))

@@ -144,8 +144,8 @@ def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=
     a.beta = float(beta)
     a.tile_hint = int(tile)
     a.colscale_n, a.colscale = (0, 1.0) if colscale is None else (int(colscale[0]), float(colscale[1]))
-    a.save_dact = None if save_dact is None else _dev_rows(save_dact, BF, "save_dact").data_ptr()    # row pitch = ldc
-    a.mul = None if mul is None else _dev_rows(mul, BF, "mul").data_ptr()                            # row pitch = ldc
+    a.save_dact = None if save_dact is None else _dev_rows(save_dact, torch.int16, "save_dact").data_ptr()    # int16 q14, row pitch = ldc
+    a.mul = None if mul is None else _dev_rows(mul, torch.int16, "mul").data_ptr()                   # int16 q14, row pitch = ldc
     return 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0)
 
 

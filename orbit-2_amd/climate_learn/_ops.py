@@ -181,11 +181,18 @@ def _ld(t, n):
     return t.stride(0) if t.dim() == 2 else n
 
 
-def _rows(M, N, device):
-    """[M, N] bf16 with the row pitch of _ld_pad (a view when padded: every consumer takes the leading dimension from stride(0))"""
+def _rows(M, N, device, dtype=BF):
+    """[M, N] bf16 (or int16: a GELU-backward factor tensor) with the row pitch of _ld_pad (a view when padded: every consumer
+    takes the leading dimension from stride(0))"""
     ld = _ld_pad(N)
-    buf = torch.empty(M, ld, dtype=BF, device=device)
+    buf = torch.empty(M, ld, dtype=dtype, device=device)
     return buf if ld == N else buf[:, :N]
+
+
+def _gelu_saved_dtype(p):
+    """what a GELU layer's forward keeps for its backward: the q14 fixed-point factor GELU'(pre) x dropout factor (int16,
+    save_dact / mul) or, beyond that format's range, the bf16 pre-activation (save_pre / dgelu_pre)"""
+    return torch.int16 if _dact_ok(p) else BF
 
 
 def _linear_fwd(x2d, W, b, M, N, K, pad=False, **kw):
@@ -350,7 +357,7 @@ class BlockFn(torch.autograd.Function):
         # by -- GELU'(pre-activation) x dropout factor, computed in fc1's epilogue where both are in registers (save_dact) --
         # not the pre-activation itself: the fc2 input gradient then has a one-multiply epilogue (4-wave kernel) instead of
         # GELU' + the mask again (reference: autograd of mlp.py:64-65)
-        pre = _rows(M, hid, x2d.device)
+        pre = _rows(M, hid, x2d.device, _gelu_saved_dtype(p_mlp))      # the factor tensor (int16 q14) or the pre-activation
         hm = _linear_fwd(h2, w1, b1, M, hid, D, pad=True, **_gelu_fwd_kw(pre, p_mlp, s1))
         if grp is None:
             x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
@@ -441,7 +448,7 @@ class ChainFn(torch.autograd.Function):
                 saved.append(h)
             else:
                 s = seeds.next() if p_mid > 0 else 0
-                pre = torch.empty(M, N, dtype=BF, device=x.device)
+                pre = torch.empty(M, N, dtype=_gelu_saved_dtype(p_mid), device=x.device)
                 y = _linear_fwd(h, W, b, M, N, K, **_gelu_fwd_kw(pre, p_mid, s))
                 saved += [h, pre]
             sds.append(s)

@@ -105,6 +105,37 @@ def tiled_predict(mm, x, y, in_variables, out_variables, div: int, overlap: int,
     return preds
 
 
+def psnr_ssim(groundtruth, pred, win: int = 7):
+    """Goodness of fit of a stitched field, as the reference prints it (utils/visualize.py:366-372: scikit-image's
+    peak_signal_noise_ratio and structural_similarity with data_range = max - min of the ground truth).
+    PSNR = 10 log10(range^2 / MSE) (closed form); the squared error sum comes from the evaluation-moment kernel
+    (orbit2_eval_moments) when the fields are device tensors.  SSIM is restated from the published definition with
+    scikit-image's defaults (7 x 7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance, mean over the map without its
+    3-pixel border); scikit-image is absent from this image, so that part is *parity unpinned* (SURVEY 8c)."""
+    from scipy.ndimage import uniform_filter
+    if torch.is_tensor(groundtruth) and groundtruth.is_cuda:
+        from .. import _hip
+        g4, p4 = groundtruth.reshape(1, 1, *groundtruth.shape[-2:]).float().contiguous(), pred.reshape(1, 1, *pred.shape[-2:]).float().contiguous()
+        mom = _hip.eval_moments(p4, g4)                         # [1, 1, 12]: index 5 = sum (pred - truth)^2
+        mse = float(mom[0, 0, 5]) / g4[0, 0].numel()
+        hr, sr = groundtruth.detach().cpu().double().numpy(), pred.detach().cpu().double().numpy()
+    else:
+        hr, sr = np.asarray(groundtruth, dtype=np.float64), np.asarray(pred, dtype=np.float64)
+        mse = float(((hr - sr) ** 2).mean())
+    hr, sr = hr.reshape(hr.shape[-2:]), sr.reshape(sr.shape[-2:])
+    rng = float(hr.max() - hr.min())
+    psnr = float("inf") if mse == 0 else 10.0 * np.log10(rng * rng / mse)
+    npx = win * win
+    cov_norm = npx / (npx - 1.0)
+    ux, uy = uniform_filter(hr, size=win), uniform_filter(sr, size=win)
+    uxx, uyy, uxy = uniform_filter(hr * hr, size=win), uniform_filter(sr * sr, size=win), uniform_filter(hr * sr, size=win)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    c1, c2 = (0.01 * rng) ** 2, (0.03 * rng) ** 2
+    smap = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    pad = (win - 1) // 2
+    return psnr, float(smap[pad:-pad, pad:-pad].mean())
+
+
 def visualize_at_index(mm, dm, dm_vis, out_list, in_transform, out_transform, variable, src, device, div, overlap, index=0,
                        tensor_par_size=1, tensor_par_group=None, save_png: bool = True, prefix: str = ""):
     """Stitched input / prediction / ground truth of test sample `index` for `variable` (reference :38-490; the PNG
@@ -132,6 +163,9 @@ def visualize_at_index(mm, dm, dm_vis, out_list, in_transform, out_transform, va
            "groundtruths": gt.detach().cpu().numpy()}
     if "ERA5" in src or src == "PRISM" or "DAYMET" in src:
         res = {k: np.flip(v, 0).copy() for k, v in res.items()}
+    # evaluation metric of the stitched field (reference :360-372, printed the same way)
+    res["psnr"], res["ssim"] = psnr_ssim(gt, prd)
+    print("Goodness of fit: PSNR %s , SSIM %s" % (res["psnr"], res["ssim"]), flush=True)
     if save_png:
         try:
             import matplotlib

@@ -301,11 +301,13 @@ def test_gemm_epilogue_full(hip, tile, M, N):
     # applied by a one-multiply epilogue (mul): the forward output is the save_pre path's bit for bit (GELU of the bf16-rounded
     # pre-activation either way), the product equals the dgelu path's up to the factor's 2^-15
     out_d = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    dact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    dact = torch.empty(M, N, dtype=torch.int16, device="cuda")       # the factor tensor is int16 fixed point, 14 fraction bits
     hip.gemm(bf(A).cuda(), bf(W).cuda(), out_d, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_dact=dact, drop_p=p,
              seed=seed, rowscale=rs.cuda(), rows_per_scale=M // 4, residual=bf(res).cuda(), ldr=N, res_mod=L, tile=tile)
     assert torch.equal(out_d, out)
-    dact_f = dact.view(torch.int16).float().cpu() / 16384.0          # (the factor tensor is int16 fixed point, 14 fraction bits)
+    dact_f = dact.float().cpu() / 16384.0
+    with pytest.raises(Exception):                                   # a bf16 tensor is not a factor tensor
+        hip.gemm(bf(A).cuda(), bf(W).cuda(), out_d, M, N, K, K, K, N, mul=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), tile=tile)
     assert nerr(dact_f, prq.grad * mask * sc) < 3e-3
     dm = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     hip.gemm(bf(A).cuda(), bf(W).cuda(), dm, M, N, K, K, K, N, mul=dact, tile=tile)
@@ -326,14 +328,14 @@ def test_gemm_save_dact_range(hip, tile):
     bias = rt(torch.randn(N, generator=g) + 1.0)
     p, seed = 0.4, 0x1234567
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    dact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    dact = torch.empty(M, N, dtype=torch.int16, device="cuda")
     hip.gemm(bf(A).cuda(), bf(W).cuda(), out, M, N, K, K, K, N, bias=bf(bias).cuda(), act=1, save_dact=dact, drop_p=p, seed=seed,
              tile=tile)
     pre = rt(A @ W.t() + bias).requires_grad_()
     F.gelu(pre).sum().backward()
     mask, sc = keep_mask(seed, M * N, p)
     mask = torch.from_numpy(mask).view(M, N)
-    fac = dact.view(torch.int16).float().cpu() / 16384.0
+    fac = dact.float().cpu() / 16384.0
     want = pre.grad * mask * sc
     assert want.max() > 1.8 and (fac - want).abs().max() < 2e-4          # no wrap: the largest factors keep their sign
     for bad in (0.44, 0.5, 0.9):

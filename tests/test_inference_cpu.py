@@ -75,3 +75,27 @@ def test_denormalize_leaves_precipitation_alone():
     out = d(x)
     assert torch.equal(out[:, 0], x[:, 0]) and torch.allclose(out[:, 1], torch.full((2, 3, 4), 290.0))
     assert torch.allclose(d(x[0])[1], torch.full((3, 4), 290.0))          # [C,H,W] input like the reference's use
+
+
+def test_psnr_ssim_of_a_stitched_field():
+    """PSNR in closed form and SSIM restated from its published definition with scikit-image's defaults (reference
+    utils/visualize.py:366-372 calls scikit-image, absent here: the SSIM is checked against a direct window-by-window evaluation
+    of the same definition, identities and monotonicity -- parity unpinned)"""
+    from climate_learn.utils.visualize import psnr_ssim
+    rng = np.random.default_rng(0)
+    hr = rng.standard_normal((40, 56)).cumsum(0).cumsum(1) / 10.0
+    sr = hr + 0.3 * rng.standard_normal(hr.shape)
+    psnr, ssim = psnr_ssim(hr, sr)
+    R = hr.max() - hr.min()
+    assert abs(psnr - 10 * np.log10(R * R / ((hr - sr) ** 2).mean())) < 1e-9
+    # direct evaluation over every full 7 x 7 window
+    c1, c2, vals = (0.01 * R) ** 2, (0.03 * R) ** 2, []
+    for i in range(3, hr.shape[0] - 3):
+        for j in range(3, hr.shape[1] - 3):
+            a, b = hr[i - 3:i + 4, j - 3:j + 4].ravel(), sr[i - 3:i + 4, j - 3:j + 4].ravel()
+            ma, mb = a.mean(), b.mean()
+            va, vb, vab = a.var(ddof=1), b.var(ddof=1), ((a - ma) * (b - mb)).sum() / (a.size - 1)
+            vals.append((2 * ma * mb + c1) * (2 * vab + c2) / ((ma * ma + mb * mb + c1) * (va + vb + c2)))
+    assert abs(ssim - float(np.mean(vals))) < 1e-9
+    assert psnr_ssim(hr, hr)[0] == float("inf") and abs(psnr_ssim(hr, hr)[1] - 1.0) < 1e-12
+    assert psnr_ssim(hr, hr + 0.6 * rng.standard_normal(hr.shape))[1] < ssim < 1.0

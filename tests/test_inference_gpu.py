@@ -89,6 +89,8 @@ def test_visualize_at_index_returns_stitched_north_up_fields(tmp_path):
     finally:
         os.chdir(cwd)
     assert res["inputs"].shape == (32, 64) and res["preds"].shape == (128, 256) and res["groundtruths"].shape == (128, 256)
+    g64, p64 = res["groundtruths"].astype(np.float64), res["preds"].astype(np.float64)      # PSNR through orbit2_eval_moments
+    assert abs(res["psnr"] - 10 * np.log10((g64.max() - g64.min()) ** 2 / ((g64 - p64) ** 2).mean())) < 1e-3 and -1.0 <= res["ssim"] <= 1.0
     xb, yb = dm.test_dataloader()[0][:2]
     assert np.array_equal(res["groundtruths"], np.flip(yb[0, 0].numpy(), 0))       # north-up flip, precip not denormalised
     assert np.array_equal(res["inputs"], np.flip(xb[0, in_vars.index("total_precipitation_24hr")].numpy(), 0))

@@ -2,7 +2,7 @@
 # usage: mkvar.sh name "-DFLAGS"   : builds orbit-2_amd/lib/alt/name.so with attn.hip recompiled under FLAGS (other objects reused)
 set -e
 name=$1; flags=$2
-R=/root/repo
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p /tmp/var_$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $flags -c $R/orbit-2_amd/csrc/attn.hip -o /tmp/var_$name/attn.o
 objs=""
