@@ -21,6 +21,7 @@
 #include "../../include/orbit2_hip.h"
 #include "attn_fwd_asm.h"
 #include "attn_dq_asm.h"
+#include "attn_dkv_asm.h"
 
 namespace {
 
@@ -1237,6 +1238,54 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
 }
 
 // =============================================================================================
+// backward, dK and dV in one pass, d = 128, q stored pre-scaled, L % 256 == 0: the GENERATED kernel (tools/gen_attn_dkv.py)
+// =============================================================================================
+// One wave per SIMD; a wave owns 32 keys (dK^T, dV^T, its K and V fragments in the accumulator file), a workgroup 128 keys; the
+// statement is the whole kernel (schedule: the generator's header; CPU execution of the same text: tests/test_attn_dkv_asm_emu_cpu.py).
+// The compiler contributes the coordinates, the lane's key-group hash and the seed-dependent constant of the row hash
+// (o2_hash64 with a zero high index word: requires B * H * L < 2^32, checked by the launcher).
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                const float* __restrict__ nlse2, const float* __restrict__ ndelta,
+                                                                bf16_t* __restrict__ dqkv, int L, int H, unsigned thr, float fk, float fv,
+                                                                uint64_t seed_arg, int Lp) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(1024))) char smem[O2_KV_LDS_BYTES];   // 4 x [Q 16 KiB] | 4 x [dO 16 KiB] | 4 x 1 KiB of row statistics
+  const uint64_t seed = seed_arg ^ o2_seed_salt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_i, head, b;
+  attn_tile_coords(L / 128, H, tile_i, head, b);
+  const int k0 = tile_i * 128 + wave * 32;
+  const size_t tstride = (size_t)3 * H * D;
+  const char* kptr = reinterpret_cast<const char*>(qkv + ((size_t)b * L + k0) * tstride + (size_t)H * D + (size_t)head * D);
+  const char* vptr = kptr + (size_t)H * D * 2;
+  const char* qptr = reinterpret_cast<const char*>(qkv + (size_t)b * L * tstride + (size_t)head * D);
+  const char* doptr = reinterpret_cast<const char*>(dout + ((size_t)b * L * H + head) * D);
+  const char* lseptr = reinterpret_cast<const char*>(nlse2 + ((size_t)(b * H + head)) * Lp);
+  const char* dltptr = reinterpret_cast<const char*>(ndelta + ((size_t)(b * H + head)) * Lp);
+  char* okptr = reinterpret_cast<char*>(dqkv + ((size_t)b * L + k0) * tstride + (size_t)H * D + (size_t)head * D);
+  char* ovptr = okptr + (size_t)H * D * 2;
+  const uint32_t keyh = DROP ? o2_attn_keyhash(seed, (uint32_t)((k0 + (lane & 31)) >> 2)) : 0u;
+  const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+  const uint32_t hseed = s_lo ^ ((s_hi << 16) | (s_hi >> 16)) ^ (s_hi + (s_hi << 3));     // o2_hash64(seed, idx) = mix(idx ^ hseed) for idx < 2^32
+  const uint32_t rowbase = (uint32_t)((uint64_t)(b * H + head) * (uint64_t)L);
+  const uint32_t ldsb = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const int nt = L / 64, strideb = (int)(tstride * 2), dorowb = H * D * 2;
+  const uint32_t fkb = __float_as_uint(fk), fvb = __float_as_uint(fv);
+#define O2_KV_OPERANDS                                                                                                              \
+  [kptr] "s"(kptr), [vptr] "s"(vptr), [qptr] "s"(qptr), [doptr] "s"(doptr), [lseptr] "s"(lseptr), [dltptr] "s"(dltptr),            \
+      [okptr] "s"(okptr), [ovptr] "s"(ovptr), [nt] "s"(nt), [strideb] "s"(strideb), [dorowb] "s"(dorowb), [ldsb] "s"(ldsb),        \
+      [wave] "s"(wave), [thr] "s"(thr), [fk] "s"(fkb), [fv] "s"(fvb), [rowbase] "s"(rowbase), [hseed] "s"(hseed), [keyh] "v"(keyh)
+  if constexpr (DROP) {
+    asm volatile(O2_KV_ASM_DROP : : O2_KV_OPERANDS : O2_KV_CLOBBERS);
+  } else {
+    asm volatile(O2_KV_ASM_NODROP : : O2_KV_OPERANDS : O2_KV_CLOBBERS);
+  }
+#undef O2_KV_OPERANDS
+}
+
+// =============================================================================================
 // backward, dK and dV of d = 256 (interm_10b) in ONE pass: the construction of attn_bwd_dkv128_kernel at one wave per SIMD.
 // 128 keys per workgroup (4 waves x 32), 512 registers per wave: dK (128) + dV (128) accumulators, K fragments (64), the
 // wave's V rows in LDS (64 KB for the workgroup) feeding the dP MFMAs by ds_read_b128.  The LDS holds that plus two stages of
@@ -1589,6 +1638,13 @@ static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, co
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
                        seed, opmul, Lp);
+  }
+  if (DV == 128 && pre && !(flags & (ORBIT2_ATTN_NO_W4 | ORBIT2_ATTN_SPLIT_DKV)) && L % 256 == 0 && L <= O2_AF_MAX_L &&
+      (uint64_t)B * (uint64_t)H * (uint64_t)L < (1ull << 32)) {
+    // the generated one-wave-per-SIMD dK + dV kernel: 128 keys per workgroup
+    hipLaunchKernelGGL((attn_bwd_dkv_w4_kernel<DR>), dim3((unsigned)((L / 128) * H * B)), dim3(256), 0, s, q_, do_, lse, delta, dq_,
+                       L, H, thr, DR ? kgrad * dscale : kgrad, DR ? dscale : 1.0f, seed, Lp);
+    return;
   }
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,

@@ -5,7 +5,7 @@ across three statements, so OUTSIDE the statements (1) no compiler-generated v_a
 register operand at all -- on gfx950 loads, stores and LDS instructions take a[...] operands without any v_accvgpr_* -- (the fragment
 registers v128..v255 are dead behind the main loop: the compiler may use them between the statements), (3) no scratch,
 (4) 256 + 256 registers in the descriptor.
-Generated attention kernels (csrc/attn.hip, attn_fwd_w4_kernel / attn_bwd_dq_w4_kernel): the whole body is ONE statement that
+Generated attention kernels (csrc/attn.hip, attn_fwd_w4_kernel / attn_bwd_dq_w4_kernel / attn_bwd_dkv_w4_kernel): the whole body is ONE statement that
 ends the kernel: no scratch, 256 + 256 registers, nothing but s_endpgm behind the statement.
 Compiles the sources to gfx950 assembly.  Exit code 0 = clean."""
 import os, re, subprocess, sys, tempfile
@@ -54,7 +54,7 @@ def audit(hipcc="/opt/rocm/bin/hipcc"):
 def audit_attention(hipcc="/opt/rocm/bin/hipcc"):
     t = _asm_of("attn.hip", hipcc)
     found, bad = 0, []
-    for m in re.finditer(r"^(_ZN12_GLOBAL__N_1\d+attn_(?:fwd|bwd_dq)_w4_kernel\w+):", t, re.M):
+    for m in re.finditer(r"^(_ZN12_GLOBAL__N_1\d+attn_(?:fwd|bwd_dq|bwd_dkv)_w4_kernel\w+):", t, re.M):
         name, i = m.group(1), m.start()
         j = t.index(".Lfunc_end", i)
         fn = t[i:j]
@@ -76,4 +76,4 @@ if __name__ == "__main__":
     print("%d generated attention kernels audited" % fa)
     for b in ba:
         print("VIOLATION %s: code behind the statement %s, statements %d, scratch %d B, agprs %d, vgprs %d" % b)
-    sys.exit(1 if bad or ba or not found or fa != 4 else 0)
+    sys.exit(1 if bad or ba or not found or fa != 6 else 0)

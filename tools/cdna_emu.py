@@ -102,6 +102,7 @@ def parse_program(lines, binds):
         if t.endswith(":"):
             labels[t[:-1]] = len(prog)
             continue
+        t = re.sub(r"quad_perm:\[(\d),(\d),(\d),(\d)\]", r"quad_perm:\1\2\3\4", t)
         parts = t.split(None, 1)
         op = parts[0]
         ops, mods = [], {}
@@ -634,6 +635,83 @@ class Emu:
         ns[:32] = d[32:]
         self._vset(w, ops[0], nd)
         self._vset(w, ops[1], ns)
+
+    def op_v_and_b32_dpp(self, w, ops, mods):
+        """dst = src0 (lanes permuted within each quad by quad_perm) & src1"""
+        qp = [int(c) for c in mods["quad_perm"]]
+        lanes = np.arange(64)
+        sel = (lanes & ~3) + np.array(qp)[lanes & 3]
+        if self.strict:
+            self._check_waitstates(w, "v_and_b32_dpp", self._regs(ops[1:3]), self._regs([ops[0]]))
+            t = w.wtime.get(parse_reg(ops[1])[:2])
+            if t and t[1] in ("valu", "trans") and w.issue - t[0] <= 2:
+                raise EmuError("wave %d: DPP reads a register written %d slots ago (needs 2 wait states): %s" % (w.wid, w.issue - t[0], self.cur))
+        a, b = self._src(w, ops[1]), self._src(w, ops[2])
+        self._vset(w, ops[0], a[sel] & b)
+
+    def op_v_cmp_ge_u32(self, w, ops, mods):
+        if self.strict:
+            self._check_waitstates(w, "v_cmp", self._regs(ops[1:3]), [])
+        a, b = self._src(w, ops[1]).astype(np.uint64), self._src(w, ops[2]).astype(np.uint64)
+        self._set_vcc(w, a >= b)
+
+    def op_s_cmp_ge_u32(self, w, ops, mods):
+        w.scc = 1 if self._sval(w, ops[0]) >= self._sval(w, ops[1]) else 0
+
+    def op_ds_read_b32(self, w, ops, mods):
+        addr = self._lds_addr(w, ops[1], mods)
+        if np.any(addr % 4):
+            raise EmuError("ds_read_b32 misaligned: " + self.cur)
+        kind, idx, n = parse_reg(ops[0])
+        self._touch(w, (kind, idx), read=False)
+        data = self._lds_read(w, addr, 4).view(np.uint32)
+        (w.v if kind == "v" else w.a)[idx] = data[:, 0]
+        w.wtime[(kind, idx)] = (w.issue, "lds")
+        w.lgkm.append(dict(regs={(kind, idx)}, kbs=list(self._cur_kbs)))
+
+    def op_ds_write_b32(self, w, ops, mods):
+        addr = self._lds_addr(w, ops[0], mods)
+        kind, idx, n = parse_reg(ops[1])
+        if self.strict:
+            self._check_waitstates(w, "ds_write_b32", [(kind, idx)], [])
+        val = self._src(w, ops[1])
+        m = self._mask(w)
+        for l in range(64):
+            if m[l]:
+                a = int(addr[l])
+                if a % 4 or a + 4 > self.wg.lds.size:
+                    raise EmuError("ds_write_b32 address: " + self.cur)
+                self.wg.lds[a:a + 4] = np.frombuffer(struct.pack("<I", int(val[l])), dtype=np.uint8)
+        w.lgkm.append(dict(regs=set()))
+
+    def op_buffer_load_dword(self, w, ops, mods):
+        """the `offen lds` form: lane l's dword lands at M0 + 4 l"""
+        if "lds" not in mods or "offen" not in mods:
+            raise EmuError("only the `offen lds` form is modelled: " + self.cur)
+        voff = self._src(w, ops[0]).astype(np.int64)
+        kind, idx, n = parse_reg(ops[1])
+        base = (int(w.s[idx]) & 0xFFFFFFFF) | ((int(w.s[idx + 1]) & 0xFFFF) << 32)
+        src = base + voff + self._sval(w, ops[2]) + int(mods.get("offset", 0))
+        if self.strict and w.issue - w.m0_time <= M0_TO_DMA:
+            raise EmuError("wave %d: LDS-DMA right behind the write of M0: %s" % (w.wid, self.cur))
+        kbs = set()
+        for l in range(64):
+            a, d = int(src[l]), w.m0 + 4 * l
+            if a < 0 or a + 4 > self.wg.mem.size or d + 4 > self.wg.lds.size:
+                raise EmuError("wave %d: LDS-DMA (dword) out of range: %s" % (w.wid, self.cur))
+            self.wg.lds[d:d + 4] = self.wg.mem[a:a + 4]
+            kbs.add(d >> 10)
+        op = dict(regs=set(), kbs=kbs)
+        if self.strict:
+            for kb in kbs:
+                for wid, rd in self.wg.readers[kb].items():
+                    if rd["pending"] and wid == w.wid:
+                        raise EmuError("wave %d: LDS-DMA into KiB %d over its own un-waited read: %s" % (w.wid, kb, self.cur))
+                    if wid != w.wid and (rd["pending"] or not (w.epoch > rd["epoch"])):
+                        raise EmuError("wave %d: LDS-DMA into KiB %d that wave %d read with no barrier since: %s" % (w.wid, kb, wid, self.cur))
+                self.wg.readers[kb] = {}
+                self.wg.dma_state[kb] = dict(wave=w.wid, retired_epoch=None, ids=op)
+        w.vm.append(op)
 
     # ---- matrix ------------------------------------------------------------------------------------------------------------
     def op_v_mfma_f32_32x32x16_bf16(self, w, ops, mods):

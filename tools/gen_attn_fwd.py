@@ -352,6 +352,8 @@ def insert_lgkm_waits(seq, carry=()):
             pend = pend[len(pend) - n:] if n > 0 else []
         if op.startswith("ds_read"):
             pend.append(regs_of(ops[0]))
+        elif op.startswith("ds_write"):
+            pend.append(set())                      # an LDS store occupies a slot of the same counter
         out.append(ins)
     return out, pend
 
