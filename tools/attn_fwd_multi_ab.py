@@ -27,12 +27,22 @@ def t(f, n=4):
     return e0.elapsed_time(e1) / n
 med = lambda v: sorted(v)[len(v) // 2]
 fl = 4.0 * B * H * L * L * d
+BWD = "--bwd" in sys.argv
+do = torch.randn(B, L, H * d, device="cuda").to(BF)
 for p in (0.1, 0.0):
     st = {}
     for name, lib in libs:
         st[name] = (torch.empty(B, L, H * d, dtype=BF, device="cuda"), torch.empty(B, H, L, dtype=F32, device="cuda"))
     def fwd(lib, s):
         assert lib.orbit2_attn_fwd_ex(P(qkv), P(s[0]), P(s[1]), B, L, H, d, C.c_float(p), C.c_uint64(11), flags, S()) == 0
+    if BWD:      # time the backward (statistics + dQ + dK/dV) instead; the printed difference is over dqkv
+        for name, lib in libs:
+            fwd(lib, st[name])
+            lib.orbit2_attn_bwd_ws_floats.restype = C.c_int64
+            ws = torch.empty(int(lib.orbit2_attn_bwd_ws_floats(B, L, H)), dtype=F32, device="cuda")
+            st[name] = (torch.empty_like(qkv), st[name][1], st[name][0], ws)
+        def fwd(lib, s):
+            assert lib.orbit2_attn_bwd_ex(P(qkv), P(s[2]), P(do), P(s[1]), P(s[3]), P(s[0]), B, L, H, d, C.c_float(p), C.c_uint64(11), flags, S()) == 0
     for name, lib in libs:
         fwd(lib, st[name]); fwd(lib, st[name])
     torch.cuda.synchronize()

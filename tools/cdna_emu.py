@@ -121,6 +121,10 @@ def parse_program(lines, binds):
             ops = fields
             if op == "s_waitcnt":
                 ops = parts[1].split()
+        for o in ops:                      # scalar register tuples must be aligned (the assembler rejects them otherwise)
+            r = parse_reg(o)
+            if r and r[0] == "s" and ((r[2] == 2 and r[1] % 2) or (r[2] >= 4 and r[1] % 4)):
+                raise EmuError("misaligned scalar register tuple in: " + t)
         prog.append((op, ops, mods, t))
     return prog, labels
 

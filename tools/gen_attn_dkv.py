@@ -40,7 +40,7 @@ VRE, VRO, VT1, VT2, VRE2, VRO2, VT1B, VT2B = 216, 217, 218, 219, 220, 221, 222, 
 VDEQ, VDOQ, VDED, VDOD, VST, VSH, VBM, VTHS, VKEYH, VLANE, VL4 = 224, 225, 226, 227, 228, 229, 230, 231, 232, 233, 234
 TD, T0, T1, T2, T3 = 235, 252, 253, 254, 255
 S_DQ, S_DD, S_PCQ, S_PCD, S_LW, S_T, S_TBQ, S_TBD, S_NT1, S_OFQ, S_OFD, S_TMP, S_M0, S_MIX = 36, 40, 44, 48, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61
-S_X, S_Y2, S_LDS, S_H2, S_DL, S_DN, S_OFS, S_RB, S_OP = 62, 63, 64, 65, 66, 70, 74, 75, 76
+S_X, S_Y2, S_LDS, S_H2, S_OFS, S_RB, S_DL, S_DN, S_OP = 62, 63, 64, 65, 66, 67, 68, 72, 76
 
 STAT_OFF = 131072
 LDS_BYTES = STAT_OFF + 4096
