@@ -52,7 +52,7 @@ def traffic(fetch_csv, write_csv, out):
            "gemm_8phase_single": ("gemm256t_kernel",), "gemm_8phase_grouped_dw": ("gemm256t_grouped_kernel",),
            "gemm_w4_single": ("gemm256w_kernel",), "gemm_w4_grouped_dw": ("gemm256w_grouped_kernel",),
            "attn_fwd": ("attn_fwd_kernel", "attn_fwd_w4_kernel", "attn_fwd_lazy_kernel"),
-           "attn_bwd_dq": ("attn_bwd_dq_kernel", "attn_bwd_dq_w4_kernel"), "attn_bwd_dkv": ("attn_bwd_dkv_kernel", "attn_bwd_dkv128_kernel")}
+           "attn_bwd_dq": ("attn_bwd_dq_kernel", "attn_bwd_dq_w4_kernel"), "attn_bwd_dkv": ("attn_bwd_dkv_kernel", "attn_bwd_dkv128_kernel", "attn_bwd_dkv_w4_kernel")}
     acc = {k: {"FETCH_SIZE": [], "WRITE_SIZE": []} for k in fam}
     for path in (fetch_csv, write_csv):
         for r in csv.DictReader(open(path)):
