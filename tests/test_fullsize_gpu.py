@@ -150,6 +150,87 @@ def test_attention_at_the_bench_batch_last_sample(hip):
             assert torch.isfinite(dv_sum).all()
 
 
+def test_generated_attention_kernels_at_the_bench_batch(hip):
+    """the GENERATED forward / dQ / dK+dV kernels (q pre-scaled, d = 128, L % 256 == 0: csrc/attn_*_asm.h) at the bench's shape,
+    per-GPU batch 16: rows of the LAST sample (past 2^31 bytes of qkv) of out / lse / dQ and sampled keys of dK / dV against fp64
+    restatements over the whole sequence, without and with dropout (mask replica for the sampled rows / keys); the identity
+    sum_k dV[k] = sum_q dO[q]; bit-repeatability; and agreement with the compiler-scheduled kernels (ORBIT2_ATTN_NO_W4)"""
+    from tests.hashmask import ATTN_KEY_SALT, o2_hash64
+    import numpy as np
+    B, L, H, d = 16, L_, H_, 128
+    PRE = hip.ATTN_Q_PRESCALED
+    x = rnd(B, L, 3 * H * d, scale=0.7, seed=61).view(B, L, 3, H * d)
+    x[:, :, 0] = (x[:, :, 0].float() * (1.4426950408889634 / d ** 0.5)).to(BF)          # what the qkv GEMM's column scale stores
+    qkv = x.view(B, L, 3 * H * d)
+    do = rnd(B, L, H * d, seed=62)
+    b = B - 1
+    q5 = qkv.view(B, L, 3, H, d)
+    g = torch.Generator().manual_seed(19)
+    for p, seed in ((0.0, 0), (0.1, 0xABCDEF12345)):
+        out, lse = hip.attn_fwd(qkv, B, L, H, d, p, seed, flags=PRE)
+        dqkv = hip.attn_bwd(qkv, out, do, lse, B, L, H, d, p, seed, flags=PRE)
+        thr = int(p * 256 + 0.5)
+        sc = 256.0 / (256.0 - thr)
+
+        def keep(h, rows, keys):           # [len(rows), len(keys)] keep mask of (sample b, head h)
+            if thr == 0:
+                return torch.ones(len(rows), len(keys), dtype=torch.float64, device="cuda")
+            R = o2_hash64(seed, ((b * H + h) * L + rows.cpu().numpy()).astype(np.uint64)).astype(np.uint64)[:, None]
+            K = o2_hash64((seed ^ ATTN_KEY_SALT) & 0xFFFFFFFFFFFFFFFF, (keys.cpu().numpy() >> 2).astype(np.uint64)).astype(np.uint64)[None, :]
+            xx = ((R ^ K) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+            xx ^= xx >> np.uint64(16)
+            byte = (xx >> ((keys.cpu().numpy().astype(np.uint64) & np.uint64(3)) * np.uint64(8))[None, :]) & np.uint64(0xFF)
+            return torch.from_numpy((byte >= np.uint64(thr)).astype(np.float64)).cuda()
+
+        allk = torch.arange(L, device="cuda")
+        for _ in range(3):
+            h = int(torch.randint(0, H, (1,), generator=g))
+            Qt, K, V = q5[b, :, 0, h].double(), q5[b, :, 1, h].double(), q5[b, :, 2, h].double()
+            dO = do.view(B, L, H, d)[b, :, h].double()
+            rows = torch.randint(0, L, (6,), generator=g).cuda()
+            s2 = Qt[rows] @ K.t()                                     # exp2 domain
+            lse2 = torch.logsumexp(s2 * 0.6931471805599453, 1)
+            P = torch.exp(s2 * 0.6931471805599453 - lse2[:, None])
+            M = keep(h, rows, allk)
+            A = P * M * sc
+            o_ref = A @ V
+            assert float((out.view(B, L, H, d)[b, rows, h].double() - o_ref).abs().max() / o_ref.abs().max()) < 1.5e-2
+            assert float((lse[b, h, rows].double() - lse2).abs().max()) < 2e-3
+            dA = dO[rows] @ V.t()
+            delta = (dO[rows] * o_ref).sum(1)
+            dS = P * (dA * M * sc - delta[:, None])
+            dq_ref = (dS @ K) * d ** -0.5
+            got = dqkv.view(B, L, 3, H, d)[b, rows, 0, h].double()
+            assert float((got - dq_ref).abs().max() / dq_ref.abs().max()) < 3e-2
+            # sampled keys: columns of P over ALL queries (row statistics from the kernel's own lse / out)
+            keys = torch.randint(0, L, (6,), generator=g).cuda()
+            lse_all = lse[b, h].double()
+            Pk = torch.exp((Qt @ K[keys].t()) * 0.6931471805599453 - lse_all[:, None])          # [L, 6]
+            Mk = keep(h, allk, keys)
+            O_all = out.view(B, L, H, d)[b, :, h].double()
+            delta_all = (dO * O_all).sum(1)
+            dv_ref = (Pk * Mk * sc).t() @ dO
+            dAk = dO @ V[keys].t()
+            dSk = Pk * (dAk * Mk * sc - delta_all[:, None])
+            dk_ref = (dSk.t() @ Qt) * 0.6931471805599453               # w.r.t. the unscaled k: ln 2 * dS^T q~
+            gk = dqkv.view(B, L, 3, H, d)[b, keys, 1, h].double()
+            gv = dqkv.view(B, L, 3, H, d)[b, keys, 2, h].double()
+            assert float((gv - dv_ref).abs().max() / dv_ref.abs().max()) < 3e-2
+            assert float((gk - dk_ref).abs().max() / dk_ref.abs().max()) < 3e-2
+        out2, lse2_ = hip.attn_fwd(qkv, B, L, H, d, p, seed, flags=PRE)
+        dq2 = hip.attn_bwd(qkv, out2, do, lse2_, B, L, H, d, p, seed, flags=PRE)
+        assert torch.equal(out, out2) and torch.equal(lse, lse2_) and torch.equal(dqkv, dq2)          # bit-repeatable
+        old, lse_o = hip.attn_fwd(qkv, B, L, H, d, p, seed, flags=PRE | hip.ATTN_NO_W4)
+        dq_o = hip.attn_bwd(qkv, old, do, lse_o, B, L, H, d, p, seed, flags=PRE | hip.ATTN_NO_W4)
+        assert float((out[b].float() - old[b].float()).abs().max() / old[b].float().abs().max()) < 1e-2
+        assert float((dqkv[b].float() - dq_o[b].float()).abs().max() / dq_o[b].float().abs().max()) < 2e-2
+        if p == 0.0:
+            dv_sum = dqkv.view(B, L, 3, H, d)[b, :, 2].double().sum(0)
+            do_sum = do.view(B, L, H, d)[b].double().sum(0)
+            assert float((dv_sum - do_sum).abs().max() / do_sum.abs().max()) < 2e-2
+        del out2, lse2_, dq2, old, lse_o, dq_o
+
+
 def test_layernorm_adamw_sampled(hip):
     x = rnd(M_, D_, scale=2.0, seed=41)
     gam, bet = rnd(D_, seed=42), rnd(D_, seed=43)
