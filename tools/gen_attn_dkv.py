@@ -34,8 +34,10 @@ S_ = [32, 64]
 DP = [48, 80]
 PD = [96, 112]
 DS = [104, 120]
-QT, DOT, NDL = 128, 160, 192
-HM, RHR = 208, 212
+QT, DOT = 128, 160
+NDL = [192, 8]          # -delta / dscale per element of the stream's unit: two sets (a unit's are fetched one phase ahead)
+HM = 208
+RHR = [212, 24]         # the quad's four row hashes, likewise
 VRE, VRO, VT1, VT2, VRE2, VRO2, VT1B, VT2B = 216, 217, 218, 219, 220, 221, 222, 223
 VDEQ, VDOQ, VDED, VDOD, VST, VSH, VBM, VTHS, VKEYH, VLANE, VL4 = 224, 225, 226, 227, 228, 229, 230, 231, 232, 233, 234
 TD, T0, T1, T2, T3 = 235, 252, 253, 254, 255
@@ -95,20 +97,21 @@ def init_reads(par, slot, half):
     return out
 
 
-def stream_prep(slot, half, drop):
-    """what the stream of a unit needs from the statistics slot: -delta / dscale per element, the quad's four row hashes"""
+def stream_prep(par, slot, half, drop):
+    """what the stream of the unit in set `par` needs from the statistics slot: -delta / dscale per element, the quad's four row
+    hashes -- read ONE PHASE AHEAD of the stream, one instruction per gap (16 LDS reads bunched in two gaps stalled the issue)"""
     out = []
     if not drop:
         return out
     for g in range(4):
         off = slot * 1024 + (32 * half + 8 * g) * 4
-        out.append("ds_read_b128 %s, %s offset:%d" % (V(NDL + 4 * g, 4), V(VST), off + 256))
-        out.append("ds_read_b32 %s, %s offset:%d" % (V(RHR + g), V(VSH), off + 512))
+        out.append("ds_read_b128 %s, %s offset:%d" % (V(NDL[par] + 4 * g, 4), V(VST), off + 256))
+        out.append("ds_read_b32 %s, %s offset:%d" % (V(RHR[par] + g), V(VSH), off + 512))
     return out
 
 
-def mix(g):
-    return ["v_xor_b32 %s, %s, %s" % (V(HM + g), V(RHR + g), V(VKEYH)),
+def mix(g, par):
+    return ["v_xor_b32 %s, %s, %s" % (V(HM + g), V(RHR[par] + g), V(VKEYH)),
             "v_mul_lo_u32 %s, %s, %s" % (V(HM + g), V(HM + g), S(S_MIX)),
             "v_lshrrev_b32 %s, 16, %s" % (V(TD), V(HM + g)),
             "v_xor_b32 %s, %s, %s" % (V(HM + g), V(HM + g), V(TD))]
@@ -120,19 +123,19 @@ def stream_gaps(par, drop, g0=4):
     sb, db = S_[par], DP[par]
     eg = lambda i: g0 + ((31 - g0 - 1) * i) // 15
     if drop:
-        m0 = mix(0)
+        m0 = mix(0, par)
         gaps[g0 - 2] += m0[:2]
         gaps[g0 - 1] += m0[2:]
     for i in range(16):
         g, gl, e = eg(i), i >> 2, i & 3
         if drop and e == 0 and gl + 1 < 4:
-            for k, ins in enumerate(mix(gl + 1)):
+            for k, ins in enumerate(mix(gl + 1, par)):
                 gaps[min(31, g + k)].append(ins)
         gaps[g].append("v_exp_f32 %s, %s" % (V(sb + i), V(sb + i)))
         if drop:
             gaps[g].append("v_and_b32_dpp %s, %s, %s quad_perm:[%d,%d,%d,%d] row_mask:0xf bank_mask:0xf" % (V(T3), V(HM + gl), V(VBM), e, e, e, e))
             gaps[g].append("v_cmp_ge_u32 vcc, %s, %s" % (V(T3), V(VTHS)))
-            gaps[g].append("v_cndmask_b32 %s, %s, %s, vcc" % (V(db + i), V(NDL + i), V(db + i)))
+            gaps[g].append("v_cndmask_b32 %s, %s, %s, vcc" % (V(db + i), V(NDL[par] + i), V(db + i)))
         gaps[g + 1].append("v_mul_f32 %s, %s, %s" % (V(db + i), V(sb + i), V(db + i)))
         if drop:
             gaps[g + 1].append("v_cndmask_b32 %s, 0, %s, vcc" % (V(sb + i), V(sb + i)))
@@ -208,8 +211,10 @@ def phase(u, drop, cfg):
     gaps = stream_gaps(par ^ 1, drop)
     if cfg.get("abl_valu"):
         gaps = [[] for _ in range(32)]
-    add(0, init_reads(par, slot, half))
-    add(1, stream_prep(s_slot, s_half, drop))
+    for k, ins in enumerate(init_reads(par, slot, half)):            # needed by the chains' first MFMAs (slot 16)
+        add(k, ins)
+    for k, ins in enumerate(stream_prep(par, slot, half, drop)):       # for unit u's stream, which runs in the NEXT phase
+        add(18 + k, ins)
     if half == 0:
         # tile t's barrier: tile t + 1 (and its statistics) have landed for every wave; the slot written next held tile t - 2
         add(2, ["s_waitcnt vmcnt(0)", "s_barrier"] + tile_offsets(2))
@@ -221,7 +226,9 @@ def phase(u, drop, cfg):
         add(g, stats_stage((slot + 2) & 3, "u%d" % u, drop))
     # re-fills: Q^T / dO^T of unit u - 1 behind the dV / dK MFMAs (slots 0..15), Q / dO rows of unit u + 1 behind the chains
     for j in range(8):
-        add(2 * j + 1 + cfg["lag"], tr_reads(j, s_slot, s_half))
+        tr = tr_reads(j, s_slot, s_half)
+        add(2 * j + 1 + cfg["lag"], tr[:2])
+        add(2 * j + 2 + cfg["lag"], tr[2:])
     nu = (u + 1) % 8
     for ds in range(8):
         add(min(31, 16 + 2 * ds + 1 + cfg["lag"]), row_reads(ds, (nu >> 1) & 3, nu & 1))
@@ -344,10 +351,10 @@ def prologue(drop):
     for r in range(16):
         e("v_mov_b32 %s, 0xf149f2ca" % V(S_[1] + r))
         e("v_mov_b32 %s, 0" % V(DP[1] + r))
-        e("v_mov_b32 %s, 0" % V(NDL + r))
+        e("v_mov_b32 %s, 0" % V(NDL[1] + r))
     for r in range(4):
         e("v_mov_b32 %s, 0" % V(HM + r))
-        e("v_mov_b32 %s, 0" % V(RHR + r))
+        e("v_mov_b32 %s, 0" % V(RHR[1] + r))
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_barrier")
     for ds in range(8):
@@ -434,9 +441,11 @@ def gen(drop, cfg=None):
     L += ["s_cmp_lt_u32 %s, %%[nt]" % S(S_T), "s_cbranch_scc1 o2kv_loop_%="]
     # tail (units 2 nt - 2 in set 0 ... wait for its packs; 2 nt - 1 in set 1): phase 2 nt = dV / dK of unit 2 nt - 2 with the
     # stream of unit 2 nt - 1 in its gaps and that unit's transposed fragments re-filled; then dV / dK of unit 2 nt - 1
-    fixed = {1: stream_prep(3, 1, drop)}
+    fixed = {}
     for j in range(8):
-        fixed.setdefault(2 * j + 1, []).extend(tr_reads(j, 3, 1))
+        tr = tr_reads(j, 3, 1)
+        fixed.setdefault(2 * j + 1, []).extend(tr[:2])
+        fixed.setdefault(min(15, 2 * j + 2), []).extend(tr[2:])
     g = stream_gaps(1, drop)
     t0 = place(acc_mfmas(0), g[:16], fixed)
     t0 += [x for gg in g[16:] for x in gg + ["s_nop 0"]] + ["s_nop 3"]      # (no MFMA between these gaps: keep exp2 results one slot apart)
