@@ -81,7 +81,8 @@ struct Epi {
   int colscale_n;      // columns n < colscale_n are multiplied by colscale right after the bias (0: none)
   float colscale;
   bf16_t* save_dact;   // GELU'(pre) x dropout factor of the element, for the backward (see include/orbit2_hip.h)
-  const bf16_t* mul;   // elementwise bf16 multiplier
+  const bf16_t* mul;   // elementwise multiplier: the q14 factor tensor written through save_dact
+  float rs_tile;       // (kernel-internal) the tile's row scale when the epilogue kind is 2
 };
 
 __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
@@ -216,18 +217,26 @@ __device__ __forceinline__ void epi8_load(const Epi& e, int m, int n, Pre8& q) {
   if (e.beta != 0.f) q.old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(e.C) + off);
 }
 
+// EK: 0 = every option of Epi is a runtime test (uniform branches: fine with two waves per SIMD, a serial chain with one);
+// 1 / 2 / 3 = the three hot combinations of the Block on whole tiles, decided by the host (w4_epi_kind) and folded at compile
+// time so that the 4-wave kernel's epilogue is straight-line code the compiler can interleave across rows:
+//   1: bias + GELU + saved GELU' factor + dropout (fc1 forward)      2: bias + dropout + row scale (one per tile) + residual
+//   3: x saved factor (fc2 input gradient)                              (proj / fc2 forward)
+// Same expressions in the same order as EK = 0: the bits do not depend on the path.
+#define O2_OPT(on_kinds, runtime) (EK == 0 ? (runtime) : (on_kinds))
+template <int EK = 0>
 __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v, const float* bias8, const Pre8& q) {
-  if (m >= e.M || n >= e.N) return;
+  if (EK == 0 && (m >= e.M || n >= e.N)) return;
   const size_t off = (size_t)m * e.ldc + n;
-  if (e.bias) {
+  if (O2_OPT(EK == 1 || EK == 2, e.bias != nullptr)) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] += bias8[k];
   }
-  if (n < e.colscale_n) {
+  if (O2_OPT(false, n < e.colscale_n)) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= e.colscale;
   }
-  if (e.save_pre) {
+  if (O2_OPT(false, e.save_pre != nullptr)) {
     const u32x4 o = pack8(v);
     *reinterpret_cast<u32x4*>(e.save_pre + off) = o;
     unpack8(o, v);   // the backward recomputes GELU'(pre) from the ROUNDED value: round here too
@@ -235,28 +244,28 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
   float dact[8];
   // (GELU of the bf16-ROUNDED pre-activation, as with save_pre: the forward's bits do not depend on which of the two the
   // caller asked for)
-  if (e.save_dact && !e.save_pre) { const u32x4 o_ = pack8(v); unpack8(o_, v); }
-  if (e.act == 1) {
-    if (e.save_dact) {
+  if (O2_OPT(EK == 1, e.save_dact && !e.save_pre)) { const u32x4 o_ = pack8(v); unpack8(o_, v); }
+  if (O2_OPT(EK == 1, e.act == 1)) {
+    if (O2_OPT(EK == 1, e.save_dact != nullptr)) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) gelu_both(v[k], v[k], dact[k]);
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
     }
-  } else if (e.act == 2) {
+  } else if (O2_OPT(false, e.act == 2)) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
   }
   float r8[8];
-  if (e.residual) {
+  if (O2_OPT(EK == 2, e.residual != nullptr)) {
     unpack8(q.res, r8);
-    if (e.res_first) {
+    if (O2_OPT(false, e.res_first != 0)) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += r8[k];
     }
   }
-  if (e.thr) {
+  if (O2_OPT(EK == 1 || EK == 2, e.thr != 0)) {
     const uint64_t idx = ((uint64_t)m * (uint64_t)e.N + (uint64_t)n) >> 2;
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
@@ -265,39 +274,41 @@ __device__ __forceinline__ void epi8_finish(const Epi& e, int m, int n, float* v
       for (int j = 0; j < 4; ++j) {
         const bool keep = ((h >> (8 * j)) & 0xffu) >= e.thr;
         v[4 * hlf + j] = keep ? v[4 * hlf + j] * e.dscale : 0.f;
-        if (e.save_dact) dact[4 * hlf + j] = keep ? dact[4 * hlf + j] * e.dscale : 0.f;
+        if (O2_OPT(EK == 1, e.save_dact != nullptr)) dact[4 * hlf + j] = keep ? dact[4 * hlf + j] * e.dscale : 0.f;
       }
     }
   }
-  if (e.save_dact) {
+  if (O2_OPT(EK == 1, e.save_dact != nullptr)) {
     u32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = pack_q14(dact[2 * k], dact[2 * k + 1]);
     *reinterpret_cast<u32x4*>(e.save_dact + off) = o;
   }
-  if (e.mul) {
+  if (O2_OPT(EK == 3, e.mul != nullptr)) {
     float m8[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) unpack_q14(q.pre[k], m8[2 * k], m8[2 * k + 1]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= m8[k];
   }
-  if (e.dgelu_pre) {
+  if (O2_OPT(false, e.dgelu_pre != nullptr)) {
     float p8[8];
     unpack8(q.pre, p8);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast(p8[k]);
   }
-  if (e.rowscale) {
-    const float s = e.rowscale[m / e.rows_per_scale];
+  if (O2_OPT(EK == 2, e.rowscale != nullptr)) {
+    const float s = EK == 2 ? e.rs_tile : e.rowscale[m / e.rows_per_scale];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= s;
   }
-  if (e.residual && !e.res_first) {
+  if (O2_OPT(EK == 2, e.residual && !e.res_first)) {
+#pragma clang fp contract(off)   // with the options folded (EK == 2) the row scale's multiply is adjacent: no fused multiply-add here,
+                                 // the runtime form has none (the two lie in different blocks) and the bits must not depend on the path
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] += r8[k];
   }
-  if (e.beta != 0.f) {
+  if (O2_OPT(false, e.beta != 0.f)) {
     float o8[8];
     unpack8(q.old, o8);
 #pragma unroll
@@ -817,7 +828,7 @@ __device__ __forceinline__ void w4_generic_finish(const Epi& epi, const char* sm
 
 // FORM: 0 = NT (A, B K-contiguous), 1 = NN (B K-strided: the stored weight in dX = dY.W), 2 = TN (both K-strided: dW = dY^T.X),
 // 3 = TT.  STAMP (diagnostic build only): per-segment cycle sums of the loop into o2_dbg_w4.
-template <int FORM, bool STAMP>
+template <int FORM, bool STAMP, int EK = 0>
 __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
                                               int K, int lda, int ldb, int tiles_m, int tiles_n, const Epi& epi, int id,
                                               char* smem) {
@@ -918,6 +929,48 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   float bias8[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) bias8[k] = 0.f;
+  if constexpr (EK != 0) {
+    // compile-time epilogue kind (epi8_finish<EK>): the pass's 16 rows per lane as straight-line code, four rows interleaved;
+    // what a row loads from memory (residual / factor) is ALL put in flight before the accumulators are staged -- 64 KiB per
+    // CU against the 16 KiB of the runtime form, whose (load, LDS read, ~300 dependent vector instructions, store) chain per
+    // two rows ran one wave per SIMD at a quarter of its vector rate (profiles/r04_gemm_epilogue_parts.txt)
+    Epi ek = epi;
+    if (EK == 2) ek.rs_tile = epi.rowscale[m0 / epi.rows_per_scale];
+    if (EK == 1 || EK == 2) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
+    const int r8 = tid >> 5, q = tid & 31;
+    constexpr int UNR = EK == 1 ? 4 : 16;              // (2 / 3: short rows, and ld[] must stay in registers)
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+      u32x4 ld[16];
+      if (EK == 2 || EK == 3) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int lr = g * 8 + r8;
+          const int m = m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
+          ld[g] = EK == 2 ? *reinterpret_cast<const u32x4*>(epi.residual + (size_t)m * epi.ldr + ne)
+                          : *reinterpret_cast<const u32x4*>(epi.mul + (size_t)m * epi.ldc + ne);
+        }
+      }
+      __syncthreads();
+      if (hh == 0) asm volatile(O2_W4_CSTAGE0 : : [be] "v"(be), [bo] "v"(bo) : "memory");
+      else asm volatile(O2_W4_CSTAGE1 : : [be] "v"(be), [bo] "v"(bo) : "memory");
+      __syncthreads();
+#pragma unroll UNR
+      for (int g = 0; g < 16; ++g) {
+        const int lr = g * 8 + r8;                       // (lr & 7) == r8
+        const int m = m0 + (lr >> 6) * 128 + hh * 64 + (lr & 63);
+        const char* row = smem + lr * 1024;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * q) ^ r8) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * q + 1) ^ r8) << 4));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        Pre8 pq;
+        if (EK == 2) pq.res = ld[g];
+        if (EK == 3) pq.pre = ld[g];
+        epi8_finish<EK>(ek, m, ne, v, bias8, pq);
+      }
+    }
+    return;
+  }
   if (generic && epi.bias) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
 #pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
@@ -957,12 +1010,23 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
 #undef O2_TS
 }
 
-template <int FORM, bool STAMP>
+template <int FORM, bool STAMP, int EK = 0>
 __global__ __launch_bounds__(256, 1) void gemm256w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                           int M, int N, int K, int lda, int ldb, int tiles_m,
                                                           int tiles_n, Epi epi) {
   __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
-  gemm256w_tile<FORM, STAMP>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+  gemm256w_tile<FORM, STAMP, EK>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+}
+
+// the epilogue kind of epi8_finish a whole-tile bf16 problem qualifies for (0: the runtime form)
+static int w4_epi_kind(const Epi& e) {
+  if (e.out_fp32 || e.save_pre || e.dgelu_pre || e.beta != 0.f || e.colscale_n > 0 || e.res_first || e.res_mod > 0 || e.act == 2) return 0;
+  if (e.bias && e.act == 1 && e.save_dact && e.thr && !e.residual && !e.rowscale && !e.mul) return 1;
+  if (e.bias && e.act == 0 && e.thr && e.residual && e.rowscale && e.rows_per_scale % 256 == 0 && !e.mul && !e.save_dact &&
+      e.ldr % 8 == 0 && !((uintptr_t)e.residual & 15))
+    return 2;
+  if (!e.bias && e.act == 0 && !e.thr && !e.residual && !e.rowscale && e.mul && !e.save_dact) return 3;
+  return 0;
 }
 
 template <int FORM>
@@ -1124,6 +1188,7 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   e.thr = (unsigned)(a->drop_p * 256.0f + 0.5f);
   e.dscale = 256.0f / (256.0f - (float)e.thr);
   e.beta = a->beta;
+  e.rs_tile = 1.0f;
   return O2_OK;
 }
 
@@ -1197,7 +1262,7 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
   if (tile == 257 || tile == 258) tile = 256;       // hints of the round-2 A/B tools: the same kernel
-  if (tile != 128 && tile != 256 && tile != 260 && tile != 261) {
+  if (tile != 128 && tile != 256 && tile != 260 && tile != 261 && tile != 262) {
     // measured on MI355X (tools/gemm_p8_ab.py, tools/gemm_t8_ab.py, tools/gemm_w4_ab.py; profiles/r02_gemm_*, r03_gemm_w4_*): a
     // 256-tile kernel wins in every operand form whenever its tiles fill the chip -- the 4-wave kernel on whole tiles
     // (+7 ... +16 % over the 8-phase kernel), the 8-phase kernel on ragged M / N; the 128^2 kernel (2 workgroups/CU, ragged K)
@@ -1209,17 +1274,27 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
     // instructions at half the rate two waves reach, so GELU / GELU' / dropout epilogues (~35 instructions per value) cost it
     // more than its main loop gains (profiles/r03_gemm_w4_epilogues.txt); K-contiguous operands whose rows are BOTH a
     // multiple of 8 KiB apart (fc2-shaped: every row's k-offset on the same memory channel) also stay on the 8-phase kernel
-    const bool heavy = e.act != 0 || e.thr != 0 || e.dgelu_pre != nullptr;
+    // (the three hot heavy combinations have compile-time epilogues there -- w4_epi_kind -- and do go to it)
+    const int form_ = a->a_kc ? (a->b_kc ? 0 : 1) : (a->b_kc ? 3 : 2);
+    const int ek_ = w4_epi_kind(e);
+    const bool heavy = (e.act != 0 || e.thr != 0 || e.dgelu_pre != nullptr) && !((ek_ == 1 || ek_ == 2) && form_ == 0);
     const bool camped = a->a_kc && a->b_kc && a->K >= 8192 && a->lda % 4096 == 0 && a->ldb % 4096 == 0;
     if (tile == 256 && a->M % 256 == 0 && a->N % 256 == 0 && !heavy && !camped) tile = 260;
   }
+  const bool w4_runtime_epi = tile == 262;             // hint 262: the 4-wave kernel with the runtime epilogue (A/B, bit-identity tests)
+  if (tile == 262) tile = 260;
   if (tile == 260 || tile == 261) {                   // 4-wave kernel: whole tiles (261: its stamped diagnostic form)
     if (a->M % 256 || a->N % 256 || a->K % BK3) return O2_ERR_ARG;
     const int tiles_m = a->M / BM2, tiles_n = a->N / BN2;
     const dim3 grid(tiles_m * tiles_n), block(256);
     const int form = a->a_kc ? (a->b_kc ? 0 : 1) : (a->b_kc ? 3 : 2);
 #define O2_W4_LAUNCH(F, S) hipLaunchKernelGGL((gemm256w_kernel<F, S>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb, tiles_m, tiles_n, e)
-    if (tile == 260) {
+    const int ek = w4_runtime_epi ? 0 : w4_epi_kind(e);
+#define O2_W4_LAUNCH_EK(F, EKV) hipLaunchKernelGGL((gemm256w_kernel<F, false, EKV>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb, tiles_m, tiles_n, e)
+    if (tile == 260 && form == 0 && ek == 1) { O2_W4_LAUNCH_EK(0, 1); }
+    else if (tile == 260 && form == 0 && ek == 2) { O2_W4_LAUNCH_EK(0, 2); }
+    else if (tile == 260 && form == 1 && ek == 3) { O2_W4_LAUNCH_EK(1, 3); }
+    else if (tile == 260) {
       switch (form) {
         case 0: O2_W4_LAUNCH(0, false); break;
         case 1: O2_W4_LAUNCH(1, false); break;
@@ -1239,6 +1314,7 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
 #endif
     }
 #undef O2_W4_LAUNCH
+#undef O2_W4_LAUNCH_EK
     O2_CHECK_LAUNCH();
     return O2_OK;
   }

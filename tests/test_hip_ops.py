@@ -344,6 +344,48 @@ def test_gemm_save_dact_range(hip, tile):
                      seed=seed, tile=tile)
 
 
+@pytest.mark.parametrize("K", [128, 448])
+def test_gemm_4wave_compile_time_epilogues(hip, K):
+    """the three hot epilogue combinations of the Block have straight-line (compile-time) epilogues on the 4-wave kernel
+    (csrc/gemm.hip w4_epi_kind: 1 = bias + GELU + saved GELU' factor + dropout, 2 = bias + dropout + per-sample row scale +
+    residual, 3 = x saved factor on the NN form): each must equal, bit for bit, the same kernel's runtime epilogue (hint 262) and
+    the 8-phase kernel (256) -- outputs AND the stored factor tensor; padded row pitches as in the step"""
+    M, N, rps = 768, 512, 256
+    g = torch.Generator().manual_seed(31 + K)
+    A, W = bf(torch.randn(M, K, generator=g)).cuda(), bf(torch.randn(N, K, generator=g) * 0.3).cuda()
+    bias = bf(torch.randn(N, generator=g)).cuda()
+    res = torch.zeros(M, N + 64, dtype=torch.bfloat16, device="cuda")
+    res[:, :N] = bf(torch.randn(M, N, generator=g)).cuda()
+    rs = (torch.rand(M // rps, generator=g) + 0.5).cuda()
+    ldc = N + 64
+    got = {}
+    for tile in (260, 262, 256):
+        o1 = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+        d1 = torch.zeros(M, ldc, dtype=torch.int16, device="cuda")
+        hip.gemm(A, W, o1, M, N, K, K, K, ldc, bias=bias, act=1, save_dact=d1, drop_p=0.1, seed=77, tile=tile)
+        o2 = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(A, W, o2, M, N, K, K, K, ldc, bias=bias, drop_p=0.1, seed=78, rowscale=rs, rows_per_scale=rps, residual=res,
+                 ldr=N + 64, tile=tile)
+        # kind 3: dX[M, K2] = dY[M, N] . Wt[N, K2] (the stored weight is the K-strided operand) x factor
+        K2 = 256
+        Wt = bf(torch.randn(N, K2, generator=torch.Generator().manual_seed(5)) * 0.3).cuda()
+        o3 = torch.zeros(M, K2 + 64, dtype=torch.bfloat16, device="cuda")
+        fac = torch.zeros(M, K2 + 64, dtype=torch.int16, device="cuda")
+        fac[:, :K2] = torch.randint(-2000, 20000, (M, K2), generator=torch.Generator().manual_seed(6), dtype=torch.int16).cuda()
+        hip.gemm(o2[:, :N], Wt, o3, M, K2, N, ldc, K2, K2 + 64, a_kc=True, b_kc=False, mul=fac, tile=tile)
+        got[tile] = (o1, d1, o2, o3)
+    torch.cuda.synchronize()
+    for other in (262, 256):
+        for x, y in zip(got[260], got[other]):
+            assert torch.equal(x, y)
+    # and against the fp32 restatement (kind 2; kinds 1 / 3 are covered by test_gemm_epilogue_full / test_gemm_save_dact_range
+    # through the same epi8_finish)
+    mask, sc = keep_mask(78, M * N, 0.1)
+    want = res[:, :N].float().cpu() + rs.cpu().repeat_interleave(rps)[:, None] * \
+        (A.float().cpu() @ W.float().cpu().t() + bias.float().cpu()) * torch.from_numpy(mask).view(M, N) * sc
+    assert nerr(got[260][2][:, :N], want) < 6e-3
+
+
 @pytest.mark.parametrize("tile", [128, 256, 260])
 def test_gemm_column_scale(hip, tile):
     """colscale epilogue (the qkv Linear's q third times log2(e)/sqrt(d)): columns n < colscale_n are multiplied in fp32
