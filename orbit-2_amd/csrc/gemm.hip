@@ -220,7 +220,7 @@ __device__ __forceinline__ void epi8_load(const Epi& e, int m, int n, Pre8& q) {
 // EK: 0 = every option of Epi is a runtime test (uniform branches: fine with two waves per SIMD, a serial chain with one);
 // 1 / 2 / 3 = the three hot combinations of the Block on whole tiles, decided by the host (w4_epi_kind) and folded at compile
 // time so that the 4-wave kernel's epilogue is straight-line code the compiler can interleave across rows:
-//   1: bias + GELU + saved GELU' factor + dropout (fc1 forward)      2: bias + dropout + row scale (one per tile) + residual
+//   1: bias + GELU + saved GELU' factor + dropout (fc1 forward)      2: bias + dropout + row scale (one per tile; optional) + residual
 //   3: x saved factor (fc2 input gradient)                              (proj / fc2 forward)
 // Same expressions in the same order as EK = 0: the bits do not depend on the path.
 #define O2_OPT(on_kinds, runtime) (EK == 0 ? (runtime) : (on_kinds))
@@ -935,7 +935,7 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
     // CU against the 16 KiB of the runtime form, whose (load, LDS read, ~300 dependent vector instructions, store) chain per
     // two rows ran one wave per SIMD at a quarter of its vector rate (profiles/r04_gemm_epilogue_parts.txt)
     Epi ek = epi;
-    if (EK == 2) ek.rs_tile = epi.rowscale[m0 / epi.rows_per_scale];
+    if (EK == 2) ek.rs_tile = epi.rowscale ? epi.rowscale[m0 / epi.rows_per_scale] : 1.0f;
     if (EK == 1 || EK == 2) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
     const int r8 = tid >> 5, q = tid & 31;
     constexpr int UNR = EK == 1 ? 4 : 16;              // (2 / 3: short rows, and ld[] must stay in registers)
@@ -1021,8 +1021,10 @@ __global__ __launch_bounds__(256, 1) void gemm256w_kernel(const bf16_t* __restri
 // the epilogue kind of epi8_finish a whole-tile bf16 problem qualifies for (0: the runtime form)
 static int w4_epi_kind(const Epi& e) {
   if (e.out_fp32 || e.save_pre || e.dgelu_pre || e.beta != 0.f || e.colscale_n > 0 || e.res_first || e.res_mod > 0 || e.act == 2) return 0;
-  if (e.bias && e.act == 1 && e.save_dact && e.thr && !e.residual && !e.rowscale && !e.mul) return 1;
-  if (e.bias && e.act == 0 && e.thr && e.residual && e.rowscale && e.rows_per_scale % 256 == 0 && !e.mul && !e.save_dact &&
+  // (thr == 0 keeps everything at scale 256 / 256 and an absent row scale is a multiplication by 1.0f: both exact, so kinds 1 / 2
+  // also serve the layers without dropout or without a DropPath scale)
+  if (e.bias && e.act == 1 && e.save_dact && !e.residual && !e.rowscale && !e.mul) return 1;
+  if (e.bias && e.act == 0 && e.residual && (!e.rowscale || e.rows_per_scale % 256 == 0) && !e.mul && !e.save_dact &&
       e.ldr % 8 == 0 && !((uintptr_t)e.residual & 15))
     return 2;
   if (!e.bias && e.act == 0 && !e.thr && !e.residual && !e.rowscale && e.mul && !e.save_dact) return 3;

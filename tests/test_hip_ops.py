@@ -373,7 +373,13 @@ def test_gemm_4wave_compile_time_epilogues(hip, K):
         fac = torch.zeros(M, K2 + 64, dtype=torch.int16, device="cuda")
         fac[:, :K2] = torch.randint(-2000, 20000, (M, K2), generator=torch.Generator().manual_seed(6), dtype=torch.int16).cuda()
         hip.gemm(o2[:, :N], Wt, o3, M, K2, N, ldc, K2, K2 + 64, a_kc=True, b_kc=False, mul=fac, tile=tile)
-        got[tile] = (o1, d1, o2, o3)
+        # the same kinds without dropout / without the row scale (layers with drop-path rate 0, the head's MLP)
+        o4 = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+        d4 = torch.zeros(M, ldc, dtype=torch.int16, device="cuda")
+        hip.gemm(A, W, o4, M, N, K, K, K, ldc, bias=bias, act=1, save_dact=d4, drop_p=0.0, seed=0, tile=tile)
+        o5 = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(A, W, o5, M, N, K, K, K, ldc, bias=bias, drop_p=0.1, seed=79, residual=res, ldr=N + 64, tile=tile)
+        got[tile] = (o1, d1, o2, o3, o4, d4, o5)
     torch.cuda.synchronize()
     for other in (262, 256):
         for x, y in zip(got[260], got[other]):
