@@ -50,7 +50,8 @@ typedef struct {
   int out_fp32;            /* 0: C is bf16, 1: C is fp32 */
   float beta;              /* C = beta*C + result (gradient accumulation) */
   int tile_hint;           /* 0 = auto; tests / tuning: 128 = 128-tile kernel, 256 = 8-wave 8-phase kernel (K % 64 == 0),
-                              260 = 4-wave kernel (M, N % 256 == 0, K % 64 == 0) */
+                              260 = 4-wave kernel (M, N % 256 == 0, K % 64 == 0), 262 = 4-wave kernel with the runtime epilogue in
+                              place of the compile-time kinds */
   int colscale_n;          /* columns n < colscale_n (a multiple of 8; 0 = none) are multiplied by colscale in fp32 right after */
   float colscale;          /*   the bias: the qkv Linear stores q * log2(e)/sqrt(d) (attention.py:50,54: q * scale), rounded ONCE */
   void* save_dact;         /* int16 [M][ldc] or NULL (needs act == 1): GELU'(pre) x (kept ? 1 / (1 - p) : 0) of THIS element as signed

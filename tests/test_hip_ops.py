@@ -218,6 +218,25 @@ def test_gemm_any_row_count_when_a_is_k_contiguous(hip, M, tile):
         hip.gemm(bf(A.t().contiguous()).cuda(), bf(B).cuda(), guard, M, N, K, M + (-M) % 8, K, N, a_kc=False)
 
 
+@pytest.mark.parametrize("name,N,K,form", [("proj fwd", 1024, 1024, "nt"), ("fc2 fwd", 1024, 4096, "nt"), ("dX qkv", 1024, 3072, "nn"),
+                                             ("dX fc1", 1024, 4096, "nn"), ("dX proj", 1024, 1024, "nn"), ("ragged K", 1000, 1000, "nt")])
+def test_gemm_single_round_grids(hip, name, N, K, form):
+    """the GEMMs of BASELINE configs[1] (interm_117m, 32x64 grid, batch 8: 4096 tokens) whose 128x128 tiles make ONE round of the
+    chip (N = 1024: 256 tiles), as dispatched, with a bias + dropout epilogue, against the fp32 product"""
+    M = 4096
+    g = torch.Generator().manual_seed(N + K)
+    A, B = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g) * 0.1)
+    a_kc, b_kc = form[0] == "n", form[1] == "t"
+    Ad, Bd = bf(A).cuda(), bf(B if b_kc else B.t().contiguous()).cuda()
+    bias = bf(torch.randn(N, generator=g)).cuda()
+    o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(Ad, Bd, o, M, N, K, K, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, bias=bias, drop_p=0.1, seed=11)
+    torch.cuda.synchronize()
+    mask, sc = keep_mask(11, M * N, 0.1)
+    want = (A @ B.t() + bias.float().cpu()) * torch.from_numpy(mask).view(M, N) * sc
+    assert nerr(o, want) < 6e-3
+
+
 @pytest.mark.parametrize("form,K", [("tn", 70), ("tn", 201), ("tn", 64 + 35), ("nt", 72), ("nn", 136), ("tt", 40)])
 def test_gemm_ragged_contraction_length(hip, form, K):
     """K need not be a multiple of the 64-wide k-step: the tail is staged from a zero page (weight-gradient form:
