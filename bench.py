@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-comm-stats", action="store_true",
                     help="do not attach CommStats (timing events + collective waits on the communication stream) to the engine: "
                          "A/B of what the accounting itself costs (tools/forced_collectives_ab.sh)")
+    ap.add_argument("--no-fused-colsum", action="store_true",
+                    help="fc1's bias gradient by a separate column-sum pass over the GELU input gradient instead of the sums its "
+                         "producing GEMM leaves per tile row (A/B)")
     ap.add_argument("--eager-baseline", type=int, default=0, metavar="B",
                     help="also time the oracle (the plain-PyTorch restatement of the reference) ON THE GPU under bf16 autocast "
                          "with the framework's fused attention, per-GPU batch B: what the reference's eager PyTorch step costs "
@@ -328,6 +331,9 @@ def main():
     from climate_learn.models.hub import Res_Slim_ViT
     from climate_learn.models.hub.components.vit_blocks import Block
     from climate_learn.trainer import training_step
+    if a.no_fused_colsum:
+        from climate_learn import _ops
+        _ops._FUSE_COLSUM = False
 
     m = MODELS[a.model]
     h, w = (int(v) for v in a.grid.split("x"))

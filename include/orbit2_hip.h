@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ORBIT2_ABI_VERSION 4
+#define ORBIT2_ABI_VERSION 5
 int orbit2_abi_version(void);
 
 /* ---- bf16 MFMA GEMM with fused epilogue ------------------------------------------------
@@ -61,8 +61,14 @@ typedef struct {
                               here, where the pre-activation and the dropout decision are in registers, instead of GELU' + the
                               mask again in the backward */
   const void* mul;         /* int16 q14 [M][ldc] or NULL: multiply the result elementwise (the backward's use of a save_dact tensor) */
+  float* colsum_ws;        /* fp32 [orbit2_gemm_bf16_colsum_rows(args)][N] or NULL (ABI 5): row t receives the column sums of the STORED
+                              (bf16-rounded) output over rows 256 t .. 256 t + 255 -- the bias gradient of the layer below a GELU
+                              (autograd of mlp.py:50,63) without a second pass over the 3 GB tensor: add the rows (orbit2_colsum on the
+                              workspace).  Only the multiply-by-factor input gradient on whole tiles fills it: a call for which
+                              orbit2_gemm_bf16_colsum_rows returns 0 is refused with O2_ERR_UNSUPPORTED when colsum_ws is set */
 } orbit2_gemm_args;
 int orbit2_gemm_bf16(const orbit2_gemm_args* args, void* stream);
+int orbit2_gemm_bf16_colsum_rows(const orbit2_gemm_args* args);   /* 0: this call cannot fuse the column sums (colsum_ws must be NULL) */
 
 /* n (<= ORBIT2_GEMM_MAX_GROUP) independent problems of ONE operand form (same a_kc, b_kc) in one launch (the 256x256
  * 8-phase kernel when every problem has K % 64 == 0, M, N >= 256 and the group fills the chip; the 128x128 kernel

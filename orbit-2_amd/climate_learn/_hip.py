@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
         ("colscale", C.c_float),
         ("save_dact", C.c_void_p),
         ("mul", C.c_void_p),
+        ("colsum_ws", C.c_void_p),
     ]
 
 
@@ -57,7 +58,7 @@ def lib():
                 "liborbit2_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        if _lib.orbit2_abi_version() != 4:
+        if _lib.orbit2_abi_version() != 5:
             raise HipBackendError("liborbit2_hip.so ABI version mismatch")
     return _lib
 
@@ -146,21 +147,30 @@ def _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=
     a.colscale_n, a.colscale = (0, 1.0) if colscale is None else (int(colscale[0]), float(colscale[1]))
     a.save_dact = None if save_dact is None else _dev_rows(save_dact, torch.int16, "save_dact").data_ptr()    # int16 q14, row pitch = ldc
     a.mul = None if mul is None else _dev_rows(mul, torch.int16, "mul").data_ptr()                   # int16 q14, row pitch = ldc
+    a.colsum_ws = None
     return 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (4.0 if out.dtype == F32 else 2.0)
 
 
-def gemm(A, B, out, M, N, K, lda, ldb, ldc, **kw):
-    """out[M,N] = epilogue(A x B); see include/orbit2_hip.h:orbit2_gemm_bf16."""
+def gemm(A, B, out, M, N, K, lda, ldb, ldc, want_colsum=False, **kw):
+    """out[M,N] = epilogue(A x B); see include/orbit2_hip.h:orbit2_gemm_bf16.
+    want_colsum: returns (out, parts) -- parts = fp32 [M / 256, N] per-tile-row column sums of the stored output when this call
+    can fuse them (orbit2_gemm_bf16_colsum_rows), else None: the caller then runs `colsum` on `out` itself."""
     a = GemmArgs()
     flops, nbytes = _gemm_fill(a, A, B, out, M, N, K, lda, ldb, ldc, **kw)
+    parts = None
+    if want_colsum:
+        rows = lib().orbit2_gemm_bf16_colsum_rows(C.byref(a))
+        if rows > 0:
+            parts = torch.empty(rows, N, dtype=F32, device=out.device)
+            a.colsum_ws = parts.data_ptr()
     if timer is not None:
         e0, e1 = timer.span("gemm_bf16", flops, nbytes)
         e0.record()
         _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
         e1.record()
-        return out
-    _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
-    return out
+    else:
+        _chk(lib().orbit2_gemm_bf16(C.byref(a), _stream()), "orbit2_gemm_bf16")
+    return (out, parts) if want_colsum else out
 
 
 GEMM_MAX_GROUP = 8

@@ -208,6 +208,7 @@ def _dx(dy2d, W, M, N, K, pad=False, **kw):
     return _hip.gemm(dy2d, cw(W), out, M, K, N, _ld(dy2d, N), K, out.stride(0), a_kc=True, b_kc=False, **kw)
 
 
+_FUSE_COLSUM = True   # fc1's bias gradient from the factor-multiply GEMM's per-tile-row sums (bench.py --no-fused-colsum: A/B)
 _DW_SPLIT = 8     # K-split of a weight gradient whose output is too few tiles to fill the chip (0: off)
 
 
@@ -248,7 +249,7 @@ class _DwBatch:
     def __init__(self):
         self.problems, self.sinks, self.keep = [], [], []
 
-    def add(self, dy2d, x2d, W, b, M, N, K):
+    def add(self, dy2d, x2d, W, b, M, N, K, colsum_parts=None):
         """queues dW[N,K] = dy^T . x; returns (index of the weight result, bias result)"""
         sw = _GradSink(W)
         self.problems.append((dy2d, x2d, sw.buf, N, K, M, _ld(dy2d, N), _ld(x2d, K), K,
@@ -258,7 +259,10 @@ class _DwBatch:
         gb = None
         if b is not None:
             sb = _GradSink(b)
-            _hip.colsum(dy2d, M, N, _ld(dy2d, N), sb.buf, beta=sb.beta)
+            if colsum_parts is not None:      # per-tile-row partial sums written by the GEMM that produced dy2d (fc2's input gradient)
+                _hip.colsum(colsum_parts, colsum_parts.shape[0], N, N, sb.buf, beta=sb.beta)
+            else:
+                _hip.colsum(dy2d, M, N, _ld(dy2d, N), sb.buf, beta=sb.beta)
             gb = sb.done()
         return len(self.sinks) - 1, gb
 
@@ -389,9 +393,12 @@ class BlockFn(torch.autograd.Function):
         dym2, gb2, done2 = _drop_bwd_bias(dx2, M, D, p_mlp, s2, dp2, L, b2)      # fc2's bias gradient rides along
         i2, gb2_ = dws.add(dym2, hm, w2, None if done2 else b2, M, D, hid)
         gb2 = gb2 if done2 else gb2_
-        dpre = _dx(dym2, w2, M, D, hid, pad=True, **_gelu_bwd_kw(pre, p_mlp, s1))
+        # (fc1's bias gradient = column sums of dpre: the factor-multiply epilogue of this GEMM leaves them per tile row when it can)
+        dpre, dpre_sums = _dx(dym2, w2, M, D, hid, pad=True, want_colsum=_FUSE_COLSUM, **_gelu_bwd_kw(pre, p_mlp, s1)), None
+        if _FUSE_COLSUM:
+            dpre, dpre_sums = dpre
         del hm, pre, dym2
-        i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D)
+        i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D, colsum_parts=dpre_sums)
         dh2 = _dx(dpre, w1, M, hid, D)
         del dpre, h2
         _tp.all_reduce_sum(dh2, grp)        # column-parallel fc1: the input gradient is a partial sum per rank

@@ -83,6 +83,7 @@ struct Epi {
   bf16_t* save_dact;   // GELU'(pre) x dropout factor of the element, for the backward (see include/orbit2_hip.h)
   const bf16_t* mul;   // elementwise multiplier: the q14 factor tensor written through save_dact
   float rs_tile;       // (kernel-internal) the tile's row scale when the epilogue kind is 2
+  float* colsum_ws;    // kind 3 only: fp32 [M / 256][N], row t = column sums of the bf16-rounded output over tile row t
 };
 
 __device__ __forceinline__ void epilogue4(const Epi& e, int m, int n, f32x4 v) {
@@ -939,6 +940,7 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
     if (EK == 1 || EK == 2) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
     const int r8 = tid >> 5, q = tid & 31;
     constexpr int UNR = EK == 1 ? 4 : 16;              // (2 / 3: short rows, and ld[] must stay in registers)
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // kind 3 with colsum_ws: this lane's 8 columns over its 32 rows
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
       u32x4 ld[16];
@@ -967,7 +969,26 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
         if (EK == 2) pq.res = ld[g];
         if (EK == 3) pq.pre = ld[g];
         epi8_finish<EK>(ek, m, ne, v, bias8, pq);
+        if (EK == 3 && epi.colsum_ws) {                  // (v holds the final fp32 values: sum what was STORED, i.e. their bf16 rounding)
+          float r[8];
+          unpack8(pack8(v), r);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) csum[k] += r[k];
+        }
       }
+    }
+    if (EK == 3 && epi.colsum_ws) {
+      // the tile's column sums: 8 row groups (tid >> 5) hold partial sums of the same 256 columns -> through LDS (free now), added in
+      // a fixed order (r8 = 0..7), one fp32 row of the workspace per tile row: no atomics, reproducible
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[(r8 * 32 + q) * 8 + k] = csum[k];
+      __syncthreads();
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += red[(g * 32 + (tid >> 3)) * 8 + (tid & 7)];
+      epi.colsum_ws[(size_t)(m0 >> 8) * epi.N + n0 + tid] = t;
     }
     return;
   }
@@ -1191,12 +1212,15 @@ static int gemm_make_epi(const orbit2_gemm_args* a, Epi& e) {
   e.dscale = 256.0f / (256.0f - (float)e.thr);
   e.beta = a->beta;
   e.rs_tile = 1.0f;
+  e.colsum_ws = a->colsum_ws;
   return O2_OK;
 }
 
 extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream) {
   if (!args || n <= 0 || n > ORBIT2_GEMM_MAX_GROUP) return O2_ERR_ARG;
   if (n == 1) return orbit2_gemm_bf16(args, stream);
+  for (int i = 0; i < n; ++i)
+    if (args[i].colsum_ws) return O2_ERR_UNSUPPORTED;      // single launches only (orbit2_gemm_bf16_colsum_rows)
   GArgs g;
   g.n = n;
   // 256-tile 8-phase kernel when every problem of the group can take it and the group fills the chip; 128-tile otherwise
@@ -1252,10 +1276,27 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
   return O2_OK;
 }
 
+// does this call run on the 4-wave kernel with epilogue kind 3 (the only path that fills colsum_ws)?  Mirrors the dispatch below.
+static bool gemm_fuses_colsum(const orbit2_gemm_args* a, const Epi& e) {
+  if (!(a->a_kc && !a->b_kc) || a->M % 256 || a->N % 256 || a->K % 64 || a->K < 128 || w4_epi_kind(e) != 3) return false;
+  if (a->tile_hint == 260) return true;
+  if (a->tile_hint != 0) return false;
+  const long t256 = (long)(a->M / 256) * (a->N / 256);
+  const long rounds = (t256 + 255) / 256;
+  return t256 >= 192 && (double)t256 / (double)(rounds * 256) >= 0.70;
+}
+
+extern "C" int orbit2_gemm_bf16_colsum_rows(const orbit2_gemm_args* a) {
+  Epi e;
+  if (!a || gemm_make_epi(a, e)) return 0;
+  return gemm_fuses_colsum(a, e) ? a->M / 256 : 0;
+}
+
 extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   Epi e;
   const int rc_epi = gemm_make_epi(a, e);
   if (rc_epi) return rc_epi;
+  if (a->colsum_ws && !gemm_fuses_colsum(a, e)) return O2_ERR_UNSUPPORTED;   // ask orbit2_gemm_bf16_colsum_rows first
   hipStream_t s = (hipStream_t)stream;
   const bf16_t* A = (const bf16_t*)a->A;
   const bf16_t* B = (const bf16_t*)a->B;

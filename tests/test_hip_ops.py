@@ -411,6 +411,33 @@ def test_gemm_4wave_compile_time_epilogues(hip, K):
     assert nerr(got[260][2][:, :N], want) < 6e-3
 
 
+def test_gemm_fused_column_sums(hip):
+    """the factor-multiply input gradient on the 4-wave kernel (epilogue kind 3) also leaves, per tile row, the column sums of the
+    output it STORED (ABI 5 colsum_ws: fc1's bias gradient without a second pass over dpre): each workspace row against the sum of
+    that tile row's 256 bf16 output rows, the output itself bit-identical to the call without the workspace; calls that cannot
+    fuse say so (no workspace) and the caller falls back to orbit2_colsum"""
+    M, N, K = 768, 512, 192
+    g = torch.Generator().manual_seed(41)
+    dy = bf(torch.randn(M, K, generator=g)).cuda()
+    Wt = bf(torch.randn(K, N, generator=g) * 0.3).cuda()
+    ldc = N + 64
+    fac = torch.zeros(M, ldc, dtype=torch.int16, device="cuda")
+    fac[:, :N] = torch.randint(-2000, 20000, (M, N), generator=g, dtype=torch.int16).cuda()
+    plain = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(dy, Wt, plain, M, N, K, K, N, ldc, a_kc=True, b_kc=False, mul=fac, tile=260)
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+    o2, parts = hip.gemm(dy, Wt, out, M, N, K, K, N, ldc, a_kc=True, b_kc=False, mul=fac, tile=260, want_colsum=True)
+    torch.cuda.synchronize()
+    assert parts is not None and parts.shape == (M // 256, N) and torch.equal(out, plain)
+    want = out[:, :N].float().view(M // 256, 256, N).sum(1)
+    assert (parts - want).abs().max() <= 1e-4 * want.abs().max()
+    # not fusable: the 8-phase kernel, a bias, a ragged tile count -> no workspace, same output
+    for kw in (dict(tile=256), dict(tile=260, bias=bf(torch.randn(N, generator=g)).cuda())):
+        o3 = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+        _, p3 = hip.gemm(dy, Wt, o3, M, N, K, K, N, ldc, a_kc=True, b_kc=False, mul=fac, want_colsum=True, **kw)
+        assert p3 is None and ("bias" in kw or torch.equal(o3, plain))
+
+
 @pytest.mark.parametrize("tile", [128, 256, 260])
 def test_gemm_column_scale(hip, tile):
     """colscale epilogue (the qkv Linear's q third times log2(e)/sqrt(d)): columns n < colscale_n are multiplied in fp32
