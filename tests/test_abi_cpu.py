@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol():
 def test_gemm_args_struct_matches_header():
     from climate_learn import _hip
     # field order/size contract with the C struct (8-byte pointers, 4-byte ints/floats, 8-byte seed)
-    assert ctypes.sizeof(_hip.GemmArgs) == 176
+    assert ctypes.sizeof(_hip.GemmArgs) == 184
+    assert _hip.GemmArgs.colsum_ws.offset == 176          # ABI 5: the last field
     assert _hip.GemmArgs.seed.offset % 8 == 0
 
 
