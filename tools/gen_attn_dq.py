@@ -387,6 +387,8 @@ BASE = dict(lag=1, dstride=3)
 
 def gen(drop, cfg=None):
     cfg = BASE if cfg is None else cfg
+    if cfg.get("abl_1616") and not cfg.get("_in1616"):      # timing only, see gen_attn_fwd.to1616
+        return F.to1616(gen(drop, dict(cfg, _in1616=1)))
     L = prologue(drop)
     L.append("o2dq_loop_%=:")
     body = []

@@ -607,8 +607,32 @@ def epilogue(drop):
 BASE = dict(klag=1, vlag=1, bar=6, dstride=3, valu_first=0, valu_last=31)
 
 
+def to1616(lines):
+    """TIMING ONLY (cfg abl_1616; results are garbage): every v_mfma_f32_32x32x16_bf16 becomes two v_mfma_f32_16x16x32_bf16 of the same
+    FLOPs on the first eight registers of its accumulator block, same operand registers, same place in the stream, and the
+    softmax guard never branches -- what this schedule would run at on the other MFMA shape (profiles/r04_attn_1616_probe.txt)"""
+    import re
+    out = []
+    for l in lines:
+        m = re.match(r"v_mfma_f32_32x32x16_bf16 ([av])\[(\d+):\d+\], (\S+), (\S+), (?:([av])\[(\d+):\d+\]|0)$", l)
+        if m:
+            dk, d0, a, b, ck = m.group(1), int(m.group(2)), m.group(3), m.group(4), m.group(5)
+            for h in range(2):
+                c = "0" if ck is None else "%s[%d:%d]" % (ck, int(m.group(6)) + 4 * h, int(m.group(6)) + 4 * h + 3)
+                out.append("v_mfma_f32_16x16x32_bf16 %s[%d:%d], %s, %s, %s" % (dk, d0 + 4 * h, d0 + 4 * h + 3, a, b, c))
+        elif l.startswith("v_mfma"):
+            raise ValueError("to1616: " + l)
+        elif l.startswith("s_cbranch_vccnz o2af_fix") or l.startswith("s_cbranch_vccnz o2dq_fix"):
+            out.append("s_nop 0")
+        else:
+            out.append(l)
+    return out
+
+
 def gen(drop, cfg=None):
     cfg = BASE if cfg is None else cfg
+    if cfg.get("abl_1616") and not cfg.get("_in1616"):
+        return to1616(gen(drop, dict(cfg, _in1616=1)))
     L = prologue(drop)
     L.append("o2af_loop_%=:")
     body, fix = [], []
