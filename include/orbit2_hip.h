@@ -90,6 +90,10 @@ int orbit2_sgemm_f32_ws(const float* A, const float* B, float* C, int M, int N, 
 /* ---- LayerNorm (vit_blocks.py:46,63; res_slimvit.py:104,294): eps 1e-5, affine ------------ */
 int orbit2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                          int rows, int D, float eps, void* stream);
+/* the same with a row pitch on y (ldy >= D elements, a multiple of 8; ABI 5): the output is the A operand of the next GEMM, and
+ * rows a multiple of 8 KiB apart (D % 4096 == 0: interm_10b) put every row's k-offset on one memory channel */
+int orbit2_layernorm_fwd_ld(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                            int rows, int D, int ldy, float eps, void* stream);
 /* dx = LN'(dy) [+ dres];  dgamma/dbeta: bf16 or fp32 [D] (beta_acc accumulates).  ws: fp32 >= 2*D*nblk */
 int orbit2_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                          const void* dres, void* dx, void* dgamma, void* dbeta, int grads_fp32, float beta_acc,
@@ -127,6 +131,13 @@ int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B, int L, int
                        uint64_t seed, int flags, void* stream);
 int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                        void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, int flags, void* stream);
+/* The same two with token-row pitches (elements, multiples of 8; ABI 5): qkv[b, l] and dqkv[b, l] start at (b * L + l) * ldq
+ * (ldq >= 3 * H * d), out[b, l] at (b * L + l) * ldo (ldo >= H * d) -- these tensors are GEMM operands on the other side, and rows
+ * a multiple of 8 KiB apart put every row's k-offset on one memory channel (see orbit2_layernorm_fwd_ld).  dout stays [B, L, H, d]. */
+int orbit2_attn_fwd_ld(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
+                       uint64_t seed, int flags, int ldq, int ldo, void* stream);
+int orbit2_attn_bwd_ld(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                       void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, int flags, int ldq, int ldo, void* stream);
 
 /* ---- folded patch-embed + variable aggregation (res_slimvit.py:250-265, 205-230;
  *      patch_embed.py:44-52; attention.py:132-176) ---------------------------------------------

@@ -209,15 +209,17 @@ def sgemm(A, B, out, M, N, K, lda, ldb, ldc, ta=False, tb=False, alpha=1.0, beta
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
+    """out: optional [rows, D] bf16 destination with any row pitch (a view of a padded buffer: orbit2_layernorm_fwd_ld)"""
     _dev(x, BF, "x"); _dev(gamma, BF, "gamma"); _dev(beta, BF, "beta")
     D = x.shape[-1]
     rows = x.numel() // D
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else _dev_rows(out, BF, "out")
+    ldy = D if out is None else y.stride(0)
     mean = torch.empty(rows, dtype=F32, device=x.device)
     rstd = torch.empty(rows, dtype=F32, device=x.device)
-    _chk(lib().orbit2_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, C.c_float(eps),
-                                    _stream()), "orbit2_layernorm_fwd")
+    _chk(lib().orbit2_layernorm_fwd_ld(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, ldy, C.c_float(eps),
+                                       _stream()), "orbit2_layernorm_fwd_ld")
     return y, mean, rstd
 
 
@@ -265,32 +267,43 @@ def mall_calibration():
     torch.cuda.synchronize()
 
 
-def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0, flags=0):
-    _dev(qkv, BF, "qkv")
-    out = torch.empty(B, L, H * d, dtype=BF, device=qkv.device)
+def attn_fwd(qkv, B, L, H, d, drop_p=0.0, seed=0, flags=0, out=None):
+    """out: optional [B * L, H * d] bf16 destination with any token-row pitch (orbit2_attn_fwd_ld); default [B, L, H * d]"""
+    _dev_rows(qkv, BF, "qkv")
+    ldq = qkv.stride(0) if qkv.dim() == 2 else 3 * H * d       # [B * L, 3 * H * d] with a token-row pitch, or contiguous
+    if out is None:
+        out, ldo = torch.empty(B, L, H * d, dtype=BF, device=qkv.device), H * d
+    else:
+        out = _dev_rows(out, BF, "out")
+        ldo = out.stride(0)
     lse = torch.empty(B, H, L, dtype=F32, device=qkv.device)
     if timer is not None:
         # algorithmic bytes: qkv read once, out + lse written once
         e0, e1 = timer.span("attn_fwd", 4.0 * B * H * L * L * d, 2.0 * 4 * B * L * H * d + 4.0 * B * H * L)
         e0.record()
-    _chk(lib().orbit2_attn_fwd_ex(_p(qkv), _p(out), _p(lse), B, L, H, d, C.c_float(drop_p), C.c_uint64(seed), int(flags),
-                                  _stream()), "orbit2_attn_fwd_ex")
+    _chk(lib().orbit2_attn_fwd_ld(_p(qkv), _p(out), _p(lse), B, L, H, d, C.c_float(drop_p), C.c_uint64(seed), int(flags),
+                                  int(ldq), int(ldo), _stream()), "orbit2_attn_fwd_ld")
     if timer is not None:
         e1.record()
     return out, lse
 
 
 def attn_bwd(qkv, out, dout, lse, B, L, H, d, drop_p=0.0, seed=0, flags=0):
-    _dev(qkv, BF, "qkv"); _dev(out, BF, "out"); _dev(dout, BF, "dout"); _dev(lse, F32, "lse")
-    dqkv = torch.empty_like(qkv)
+    _dev_rows(qkv, BF, "qkv"); _dev_rows(out, BF, "out"); _dev(dout, BF, "dout"); _dev(lse, F32, "lse")
+    ldo = out.stride(0) if out.dim() == 2 else H * d           # [B * L, H * d] with a token-row pitch, or contiguous [B, L, H * d]
+    ldq = qkv.stride(0) if qkv.dim() == 2 else 3 * H * d
+    if ldq != 3 * H * d:                                        # dqkv carries qkv's pitch (it is a GEMM operand too)
+        dqkv = torch.empty(B * L, ldq, dtype=BF, device=qkv.device)[:, :3 * H * d]
+    else:
+        dqkv = torch.empty_like(qkv)
     lib().orbit2_attn_bwd_ws_floats.restype = C.c_int64
     delta = torch.empty(int(lib().orbit2_attn_bwd_ws_floats(B, L, H)), dtype=F32, device=qkv.device)
     if timer is not None:
         # algorithmic: 2x the forward's FLOPs (recompute not credited); qkv, out, dout read once, dqkv written once
         e0, e1 = timer.span("attn_bwd", 8.0 * B * H * L * L * d, 2.0 * 8 * B * L * H * d + 8.0 * B * H * L)
         e0.record()
-    _chk(lib().orbit2_attn_bwd_ex(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, L, H, d,
-                                  C.c_float(drop_p), C.c_uint64(seed), int(flags), _stream()), "orbit2_attn_bwd_ex")
+    _chk(lib().orbit2_attn_bwd_ld(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, L, H, d,
+                                  C.c_float(drop_p), C.c_uint64(seed), int(flags), int(ldq), int(ldo), _stream()), "orbit2_attn_bwd_ld")
     if timer is not None:
         e1.record()
     return dqkv

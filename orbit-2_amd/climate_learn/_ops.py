@@ -341,12 +341,13 @@ class BlockFn(torch.autograd.Function):
         p_attn, p_proj, p_mlp = ps
         sa, sp, s1, s2 = sds
         Dl = H * d                                  # = D on one rank, D / tensor_par_size under head-split
-        h1, mean1, rstd1 = _hip.layernorm_fwd(x2d, cw(n1w), cw(n1b))
+        # h1, h2 and o are GEMM A operands: they carry _ld_pad's row pitch (a no-op unless D is a multiple of 4096 -- interm_10b --
+        # where rows 16 KiB apart would put every row's k-offset on one memory channel: DESIGN 4.1)
+        h1, mean1, rstd1 = _hip.layernorm_fwd(x2d, cw(n1w), cw(n1b), out=_rows(M, D, x2d.device))
         # the q third leaves the GEMM epilogue as q * log2(e)/sqrt(d) (fp32 product, ONE rounding to bf16): the attention
         # kernels' scores are exp2 arguments with exact bf16 x bf16 products, as with the reference's fp32 scaling
-        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * Dl, D, colscale=(Dl, _Q_PRESCALE / math.sqrt(d)))
-        o, lse = _hip.attn_fwd(qkv, B, L, H, d, p_attn, sa, flags=_hip.ATTN_Q_PRESCALED)
-        o2d = o.view(M, Dl)
+        qkv = _linear_fwd(h1, wqkv, bqkv, M, 3 * Dl, D, pad=True, colscale=(Dl, _Q_PRESCALE / math.sqrt(d)))
+        o2d, lse = _hip.attn_fwd(qkv, B, L, H, d, p_attn, sa, flags=_hip.ATTN_Q_PRESCALED, out=_rows(M, Dl, x2d.device))
         if grp is None:
             x1 = _linear_fwd(o2d, wp, bp, M, D, Dl, drop_p=p_proj, seed=sp, rowscale=dp1, rows_per_scale=L,
                              residual=x2d, ldr=D)
@@ -356,7 +357,7 @@ class BlockFn(torch.autograd.Function):
             part = _linear_fwd(o2d, wp, bp, M, D, Dl, drop_p=p_proj, seed=sp)
             _tp.all_reduce_sum(part, grp)
             x1 = _hip.post_reduce(part, M, D, residual=x2d, rowscale=dp1, rows_per_scale=L)
-        h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b))
+        h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b), out=_rows(M, D, x2d.device))
         # the hidden tensors (pre, hm, and dpre in backward) carry _ld_pad's row pitch.  `pre` holds what the backward multiplies
         # by -- GELU'(pre-activation) x dropout factor, computed in fc1's epilogue where both are in registers (save_dact) --
         # not the pre-activation itself: the fc2 input gradient then has a one-multiply epilogue (4-wave kernel) instead of

@@ -132,7 +132,7 @@ __device__ __forceinline__ void attn_tile_coords(int nq, int H, int& qt, int& he
 template <int D, bool DROP, bool RAGGED, int NW>
 __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
-                                                          unsigned thr, float dscale, uint64_t seed_arg) {
+                                                          unsigned thr, float dscale, uint64_t seed_arg, int ldo, int ldq) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // [2 stages][K | V]
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
   int tile_i, head, b;
   attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
   const int q0 = tile_i * (NW * 32) + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;  // token stride in qkv
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D  // token stride in qkv
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
   const bf16_t* vbase = qbase + (size_t)2 * H * D;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
   const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
   if (!q_ok) return;
   if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
-  bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
+  bf16_t* orow = out + ((size_t)b * L + qrow) * (size_t)ldo + (size_t)head * D;   // ldo: token-row pitch of out (>= H * D)
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
 template <int D, bool RAGGED, int NW>
 __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
-                                                          unsigned thr, float dscale, uint64_t seed_arg) {
+                                                          unsigned thr, float dscale, uint64_t seed_arg, int ldo, int ldq) {
   constexpr bool DROP = false;                      // (the dropout forward is attn_fwd_kernel above)
   const uint64_t seed = seed_arg ^ o2_seed_salt;
   using C = Cfg<D>;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
   int tile_i, head, b;
   attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
   const int q0 = tile_i * (NW * 32) + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;  // token stride in qkv
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D  // token stride in qkv
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
   const bf16_t* vbase = qbase + (size_t)2 * H * D;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
   const float inv = (DROP ? dscale : 1.0f) / l_tot;   // dropout scale folded out of the inner loop
   if (!q_ok) return;
   if (hq == 0) lse[((size_t)(b * H + head)) * L + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
-  bf16_t* orow = out + ((size_t)b * L + qrow) * ((size_t)H * D) + (size_t)head * D;
+  bf16_t* orow = out + ((size_t)b * L + qrow) * (size_t)ldo + (size_t)head * D;   // ldo: token-row pitch of out (>= H * D)
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
 template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int L, int H, unsigned thr, float dscale,
-                                                            uint64_t seed_arg) {
+                                                            uint64_t seed_arg, int ldo, int ldq) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(1024))) char smem[O2_AF_LDS_BYTES(O2_AF_MAX_L)];   // [2 slots][K 16 KiB | V 16 KiB] | key-group hashes
   const uint64_t seed = seed_arg ^ o2_seed_salt;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __res
   int tile_i, head, b;
   attn_tile_coords(L / 256, H, tile_i, head, b);
   const int q0 = tile_i * 256 + wave * 64;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   if (DROP) {
     // key-group hashes of the whole sequence (they depend on neither batch nor head): position T*16 + h*8 + j holds
     // K(T*16 + 2 j + h), so lane half h reads the 8 values of its keys of tile T as two 16-byte pieces
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __res
   __syncthreads();
   const char* kptr = reinterpret_cast<const char*>(qkv + (size_t)b * L * tstride + (size_t)H * D + (size_t)head * D);
   const char* qptr = reinterpret_cast<const char*>(qkv + ((size_t)b * L + q0) * tstride + (size_t)head * D);
-  char* optr = reinterpret_cast<char*>(out + (((size_t)b * L + q0) * H + head) * D);
+  char* optr = reinterpret_cast<char*>(out + ((size_t)b * L + q0) * (size_t)ldo + (size_t)head * D);
   char* lptr = reinterpret_cast<char*>(lse + ((size_t)(b * H + head)) * L + q0);
   const uint64_t row = (uint64_t)(b * H + head) * L + (uint64_t)(q0 + (lane & 31));
   const uint32_t rhx = DROP ? o2_attn_rowhash(seed, row) : 0u, rhy = DROP ? o2_attn_rowhash(seed, row + 32) : 0u;
@@ -565,14 +565,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __res
     asm volatile(O2_AF_ASM_DROP
                  :
                  : [kptr] "s"(kptr), [qptr] "s"(qptr), [optr] "s"(optr), [lptr] "s"(lptr), [nt] "s"(nt), [strideb] "s"(strideb),
-                   [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [dscale] "s"(dsc), [orowb] "s"(hd2),
+                   [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [dscale] "s"(dsc), [orowb] "s"(ldo * 2),
                    [rhx] "v"(rhx), [rhy] "v"(rhy)
                  : O2_AF_CLOBBERS);
   } else {
     asm volatile(O2_AF_ASM_NODROP
                  :
                  : [kptr] "s"(kptr), [qptr] "s"(qptr), [optr] "s"(optr), [lptr] "s"(lptr), [nt] "s"(nt), [strideb] "s"(strideb),
-                   [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [dscale] "s"(dsc), [orowb] "s"(hd2),
+                   [hd2] "s"(hd2), [ldsb] "s"(ldsb), [wave] "s"(wave), [thr] "s"(thr), [dscale] "s"(dsc), [orowb] "s"(ldo * 2),
                    [rhx] "v"(rhx), [rhy] "v"(rhy)
                  : O2_AF_CLOBBERS);
   }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __res
 // sequence contributes exp2(s - 1e30) = 0.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, float* __restrict__ ws, int B, int L,
-                                                         int H, int D, int Lp, float inv_dscale) {
+                                                         int H, int D, int Lp, float inv_dscale, int ldo) {
   // one 16-lane group per (batch, padded token, head) row of D elements
   const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int li = threadIdx.x & 15;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     return;
   }
   const int64_t row = (bb * L + q) * H + hh;
-  const bf16_t* po = o + row * D;
+  const bf16_t* po = o + (bb * L + q) * (int64_t)ldo + (int64_t)hh * D;   // out may carry a token-row pitch; dout is contiguous
   const bf16_t* pd = dout + row * D;
   float s = 0.f;
   for (int c = li; c < D / 8; c += 16) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale,
-                                                             unsigned thr, float dscale, uint64_t seed_arg, float opmul, int Lp) {
+                                                             unsigned thr, float dscale, uint64_t seed_arg, float opmul, int Lp, int ldq) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
   int tile_i, head, b;
   attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
   const int q0 = tile_i * (NW * 32) + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
   const bf16_t* vbase = qbase + (size_t)2 * H * D;
@@ -750,7 +750,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ nlse2, const float* __restrict__ ndelta,
                                                                bf16_t* __restrict__ dqkv, int L, int H, unsigned thr, float fs,
-                                                               uint64_t seed_arg, int Lp) {
+                                                               uint64_t seed_arg, int Lp, int ldq) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(1024))) char smem[O2_DQ_LDS_BYTES(O2_AF_MAX_L)];   // 4 x [K 16 KiB] | 4 x [V 16 KiB] | key-group hashes
   const uint64_t seed = seed_arg ^ o2_seed_salt;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w4_kernel(const bf16_t* __
   int tile_i, head, b;
   attn_tile_coords(L / 256, H, tile_i, head, b);
   const int q0 = tile_i * 256 + wave * 64;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   if (DROP) {
     uint32_t* skh = reinterpret_cast<uint32_t*>(smem + O2_DQ_KH_OFF);
     for (int i = tid; i < L / 4 + 16; i += 256) {
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                               unsigned thr, float dscale, uint64_t seed_arg, float opmul,
-                                                              float kgrad, int Lp) {
+                                                              float kgrad, int Lp, int ldq) {
   const uint64_t seed = seed_arg ^ o2_seed_salt;   // see common.h: fresh masks for every replay of a captured step
   using C = Cfg<D>;
   constexpr bool DO_DK = WHICH != 2, DO_DV = WHICH != 1;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dkv_kern
   int tile_i, head, b;
   attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
   const int k0 = tile_i * (NW * 32) + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   const size_t ostride = (size_t)H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
                                                                  const float* __restrict__ delta,
                                                                  bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                                  unsigned thr, float dscale, uint64_t seed_arg, float opmul,
-                                                                 float kgrad, int Lp) {
+                                                                 float kgrad, int Lp, int ldq) {
   constexpr int D = 128, NW = 8;
   using C = Cfg<D>;
   constexpr int VOFF = 4 * C::TILE, SOFF = 8 * C::TILE;       // [2][Q|dO] | V rows of the workgroup | [2][lse2|delta|row hash]
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_kernel(const bf16_t* _
   int tile_i, head, b;
   attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
   const int k0 = tile_i * (NW * 32) + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   const size_t ostride = (size_t)H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -1248,7 +1248,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_w4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ nlse2, const float* __restrict__ ndelta,
                                                                 bf16_t* __restrict__ dqkv, int L, int H, unsigned thr, float fk, float fv,
-                                                                uint64_t seed_arg, int Lp) {
+                                                                uint64_t seed_arg, int Lp, int ldq) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(1024))) char smem[O2_KV_LDS_BYTES];   // 4 x [Q 16 KiB] | 4 x [dO 16 KiB] | 4 x 1 KiB of row statistics
   const uint64_t seed = seed_arg ^ o2_seed_salt;
@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_w4_kernel(const bf16_t* _
   int tile_i, head, b;
   attn_tile_coords(L / 128, H, tile_i, head, b);
   const int k0 = tile_i * 128 + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   const char* kptr = reinterpret_cast<const char*>(qkv + ((size_t)b * L + k0) * tstride + (size_t)H * D + (size_t)head * D);
   const char* vptr = kptr + (size_t)H * D * 2;
   const char* qptr = reinterpret_cast<const char*>(qkv + (size_t)b * L * tstride + (size_t)head * D);
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
                                                                  const float* __restrict__ delta,
                                                                  bf16_t* __restrict__ dqkv, int L, int H, float scale,
                                                                  unsigned thr, float dscale, uint64_t seed_arg, float opmul,
-                                                                 float kgrad, int Lp) {
+                                                                 float kgrad, int Lp, int ldq) {
   constexpr int D = 256, NW = 4, TR = 32;                    // TR: query rows per staged tile
   using C = Cfg<D>;
   constexpr int TILE = TR * C::RB;                           // 16 KB
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv256_kernel(const bf16_t* _
   int tile_i, head, b;
   attn_tile_coords((L + NW * 32 - 1) / (NW * 32), H, tile_i, head, b);
   const int k0 = tile_i * (NW * 32) + wave * 32;
-  const size_t tstride = (size_t)3 * H * D;
+  const size_t tstride = (size_t)ldq;      // token-row pitch of qkv (and dqkv), >= 3 * H * D
   const size_t ostride = (size_t)H * D;
   const bf16_t* qbase = qkv + (size_t)b * L * tstride + (size_t)head * D;
   const bf16_t* kbase = qbase + (size_t)H * D;
@@ -1571,21 +1571,21 @@ static int attn_waves_fwd(int L, int d, int flags) {
 
 template <int DV, bool DR, bool RG, int NW>
 static void launch_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, float sc_log2, unsigned thr, float dscale,
-                       uint64_t seed, hipStream_t s) {
+                       uint64_t seed, hipStream_t s, int ldo, int ldq) {
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
   if constexpr (!DR) {
     hipLaunchKernelGGL((attn_fwd_lazy_kernel<DV, RG, NW>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
-                       thr, dscale, seed);
+                       thr, dscale, seed, ldo, ldq);
     return;
   }
   hipLaunchKernelGGL((attn_fwd_kernel<DV, DR, RG, NW>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, sc_log2,
-                     thr, dscale, seed);
+                     thr, dscale, seed, ldo, ldq);
 }
 template <int DV, bool DR, int NW>
 static void launch_fwd_r(bool ragged, const void* qkv, void* out, float* lse, int B, int L, int H, float sc_log2, unsigned thr,
-                         float dscale, uint64_t seed, hipStream_t s) {
-  if (ragged) launch_fwd<DV, DR, true, NW>(qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);
-  else launch_fwd<DV, DR, false, NW>(qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);
+                         float dscale, uint64_t seed, hipStream_t s, int ldo, int ldq) {
+  if (ragged) launch_fwd<DV, DR, true, NW>(qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s, ldo, ldq);
+  else launch_fwd<DV, DR, false, NW>(qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s, ldo, ldq);
 }
 
 extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
@@ -1595,9 +1595,14 @@ extern "C" int orbit2_attn_fwd(const void* qkv, void* out, float* lse, int B, in
 
 extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
                                   uint64_t seed, int flags, void* stream) {
+  return orbit2_attn_fwd_ld(qkv, out, lse, B, L, H, d, drop_p, seed, flags, 3 * H * d, H * d, stream);
+}
+
+extern "C" int orbit2_attn_fwd_ld(const void* qkv, void* out, float* lse, int B, int L, int H, int d, float drop_p,
+                                  uint64_t seed, int flags, int ldq, int ldo, void* stream) {
   int rc = attn_check(qkv, out, B, L, H, d, drop_p);
   if (rc) return rc;
-  if (!lse) return O2_ERR_ARG;
+  if (!lse || ldo < H * d || (ldo & 7) || ldq < 3 * H * d || (ldq & 7)) return O2_ERR_ARG;
   // (q stored pre-scaled: the kernels' multiplier is 1)
   const float sc_log2 = (flags & ORBIT2_ATTN_Q_PRESCALED) ? 1.0f : (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
@@ -1605,8 +1610,8 @@ extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B,
   hipStream_t s = (hipStream_t)stream;
   if (d == 128 && (flags & ORBIT2_ATTN_Q_PRESCALED) && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L) {
     dim3 grid((unsigned)((L / 256) * H * B)), block(256);
-    if (thr) hipLaunchKernelGGL((attn_fwd_w4_kernel<true>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed);
-    else hipLaunchKernelGGL((attn_fwd_w4_kernel<false>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed);
+    if (thr) hipLaunchKernelGGL((attn_fwd_w4_kernel<true>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed, ldo, ldq);
+    else hipLaunchKernelGGL((attn_fwd_w4_kernel<false>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed, ldo, ldq);
     O2_CHECK_LAUNCH();
     return O2_OK;
   }
@@ -1614,8 +1619,8 @@ extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B,
   const bool ragged = (L % (nw * 32)) != 0;
 #define O2_FWD(DV, NWV)                                                                              \
   do {                                                                                               \
-    if (thr) launch_fwd_r<DV, true, NWV>(ragged, qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);  \
-    else launch_fwd_r<DV, false, NWV>(ragged, qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s);     \
+    if (thr) launch_fwd_r<DV, true, NWV>(ragged, qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s, ldo, ldq);  \
+    else launch_fwd_r<DV, false, NWV>(ragged, qkv, out, lse, B, L, H, sc_log2, thr, dscale, seed, s, ldo, ldq);     \
   } while (0)
   if (d == 256) O2_FWD(256, 4);
   else if (d == 128) { if (nw == 8) O2_FWD(128, 8); else O2_FWD(128, 4); }
@@ -1627,51 +1632,51 @@ extern "C" int orbit2_attn_fwd_ex(const void* qkv, void* out, float* lse, int B,
 
 template <int DV, bool DR, bool RG, int NW>
 static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta, bf16_t* dq_, int B, int L,
-                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s, int flags, int Lp) {
+                       int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s, int flags, int Lp, int ldq) {
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
   const bool pre = (flags & ORBIT2_ATTN_Q_PRESCALED) != 0;
   const float opmul = pre ? 1.0f : scale * 1.4426950408889634f, kgrad = pre ? 0.6931471805599453f : scale;
   if (DV == 128 && pre && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L) {
     // the generated one-wave-per-SIMD dQ kernel (256-row workgroups whatever NW is)
     hipLaunchKernelGGL((attn_bwd_dq_w4_kernel<DR>), dim3((unsigned)((L / 256) * H * B)), dim3(256), 0, s, q_, do_, lse, delta, dq_,
-                       L, H, thr, DR ? scale * dscale : scale, seed, Lp);
+                       L, H, thr, DR ? scale * dscale : scale, seed, Lp, ldq);
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DV, DR, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                       seed, opmul, Lp);
+                       seed, opmul, Lp, ldq);
   }
   if (DV == 128 && pre && !(flags & (ORBIT2_ATTN_NO_W4 | ORBIT2_ATTN_SPLIT_DKV)) && L % 256 == 0 && L <= O2_AF_MAX_L &&
       (uint64_t)B * (uint64_t)H * (uint64_t)L < (1ull << 32)) {
     // the generated one-wave-per-SIMD dK + dV kernel: 128 keys per workgroup
     hipLaunchKernelGGL((attn_bwd_dkv_w4_kernel<DR>), dim3((unsigned)((L / 128) * H * B)), dim3(256), 0, s, q_, do_, lse, delta, dq_,
-                       L, H, thr, DR ? kgrad * dscale : kgrad, DR ? dscale : 1.0f, seed, Lp);
+                       L, H, thr, DR ? kgrad * dscale : kgrad, DR ? dscale : 1.0f, seed, Lp, ldq);
     return;
   }
   if constexpr (DV == 64) {       // dK and dV in one pass (fits two waves per SIMD)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 0, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed, opmul, kgrad, Lp);
+                       dscale, seed, opmul, kgrad, Lp, ldq);
   } else if (DV == 256 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {             // one pass at one wave per SIMD (interm_10b)
     hipLaunchKernelGGL((attn_bwd_dkv256_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                       seed, opmul, kgrad, Lp);
+                       seed, opmul, kgrad, Lp, ldq);
   } else if (DV == 128 && NW == 8 && !(flags & ORBIT2_ATTN_SPLIT_DKV)) {   // one pass, V rows in LDS
     hipLaunchKernelGGL((attn_bwd_dkv128_kernel<DR, RG>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr, dscale,
-                       seed, opmul, kgrad, Lp);
+                       seed, opmul, kgrad, Lp, ldq);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 1, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed, opmul, kgrad, Lp);
+                       dscale, seed, opmul, kgrad, Lp, ldq);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DV, DR, 2, RG, NW>), grid, block, 0, s, q_, do_, lse, delta, dq_, L, H, scale, thr,
-                       dscale, seed, opmul, kgrad, Lp);
+                       dscale, seed, opmul, kgrad, Lp, ldq);
   }
 }
 template <int DV, int NW>
 static void launch_bwd_r(bool drop, bool ragged, const bf16_t* q_, const bf16_t* do_, const float* lse, const float* delta,
                          bf16_t* dq_, int B, int L, int H, float scale, unsigned thr, float dscale, uint64_t seed, hipStream_t s,
-                         int flags, int Lp) {
+                         int flags, int Lp, int ldq) {
   if (drop) {
-    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
-    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    if (ragged) launch_bwd<DV, true, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
+    else launch_bwd<DV, true, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
   } else {
-    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
-    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    if (ragged) launch_bwd<DV, false, true, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
+    else launch_bwd<DV, false, false, NW>(q_, do_, lse, delta, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
   }
 }
 
@@ -1690,9 +1695,15 @@ extern "C" int orbit2_attn_bwd(const void* qkv, const void* out, const void* dou
 extern "C" int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                                   void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, int flags,
                                   void* stream) {
+  return orbit2_attn_bwd_ld(qkv, out, dout, lse, delta, dqkv, B, L, H, d, drop_p, seed, flags, 3 * H * d, H * d, stream);
+}
+
+extern "C" int orbit2_attn_bwd_ld(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                  void* dqkv, int B, int L, int H, int d, float drop_p, uint64_t seed, int flags, int ldq,
+                                  int ldo, void* stream) {
   int rc = attn_check(qkv, out, B, L, H, d, drop_p);
   if (rc) return rc;
-  if (!dout || !lse || !delta || !dqkv) return O2_ERR_ARG;
+  if (!dout || !lse || !delta || !dqkv || ldo < H * d || (ldo & 7) || ldq < 3 * H * d || (ldq & 7)) return O2_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)d);
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
@@ -1703,20 +1714,20 @@ extern "C" int orbit2_attn_bwd_ex(const void* qkv, const void* out, const void* 
   float* ws1 = delta + (size_t)B * H * Lp;
   const int64_t nrows = (int64_t)B * Lp * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, s,
-                     (const bf16_t*)out, (const bf16_t*)dout, lse, delta, B, L, H, d, Lp, 1.0f / dscale);
+                     (const bf16_t*)out, (const bf16_t*)dout, lse, delta, B, L, H, d, Lp, 1.0f / dscale, ldo);
   O2_CHECK_LAUNCH();
   const bf16_t* q_ = (const bf16_t*)qkv;
   const bf16_t* do_ = (const bf16_t*)dout;
   bf16_t* dq_ = (bf16_t*)dqkv;
   const int nw = attn_waves(L, d, flags);
   const bool ragged = (L % (nw * 32)) != 0;
-  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+  if (d == 256) launch_bwd_r<256, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
   else if (d == 128) {
-    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
-    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    if (nw == 8) launch_bwd_r<128, 8>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
+    else launch_bwd_r<128, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
   } else {
-    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
-    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp);
+    if (nw == 8) launch_bwd_r<64, 8>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
+    else launch_bwd_r<64, 4>(thr != 0, ragged, q_, do_, ws0, ws1, dq_, B, L, H, scale, thr, dscale, seed, s, flags, Lp, ldq);
   }
   O2_CHECK_LAUNCH();
   return O2_OK;

@@ -16,7 +16,7 @@ template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
                                                      const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int D, float eps) {
+                                                     int D, float eps, int ldy) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
   const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-  bf16_t* yr = y + (size_t)row * D;
+  bf16_t* yr = y + (size_t)row * ldy;      // ldy: row pitch of y (>= D)
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ch = lane + c * 64;
@@ -660,13 +660,18 @@ inline int grid_for(int64_t work_items, int per_block) {
 
 extern "C" int orbit2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
                                     float* rstd, int rows, int D, float eps, void* stream) {
-  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXD)
+  return orbit2_layernorm_fwd_ld(x, gamma, beta, y, mean, rstd, rows, D, D, eps, stream);
+}
+
+extern "C" int orbit2_layernorm_fwd_ld(const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                                       float* rstd, int rows, int D, int ldy, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXD || ldy < D || (ldy & 7))
     return O2_ERR_ARG;
   const int nc = (D / 8 + 63) / 64;
 #define CALL(N)                                                                                              \
   hipLaunchKernelGGL(ln_fwd_kernel<N>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,              \
                      (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd,  \
-                     rows, D, eps)
+                     rows, D, eps, ldy)
   LN_DISPATCH(nc, CALL);
 #undef CALL
   O2_CHECK_LAUNCH();

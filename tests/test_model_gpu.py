@@ -579,18 +579,21 @@ def test_loss_scaler_dynamics_growth_overflow_skip_and_floor():
     assert scaler.get_scale() == 256.0 and gs.captures == 2               # grew once (3 clean steps) -> one re-capture
 
 
-def test_block_padded_hidden_pitch_is_bit_identical(monkeypatch):
+@pytest.mark.parametrize("dim,heads", [(1024, 16), (4096, 32), (4096, 16)])
+def test_block_padded_hidden_pitch_is_bit_identical(monkeypatch, dim, heads):
     """the MLP hidden tensors carry a padded row pitch when their rows would be a multiple of 8 KiB apart (_ops._ld_pad: memory-
     channel camping); a row pitch changes no arithmetic: a Block with hidden width 4096 (8 KiB rows -> padded) gives
     the same bits, forward and every gradient, with the padding switched off -- train mode (GELU + dropout + DropPath epilogues,
-    the weight-gradient group reading the padded tensors K-strided), and under activation recompute"""
+    the weight-gradient group reading the padded tensors K-strided), and under activation recompute.  At width 4096 (the
+    interm_10b case, D % 4096 == 0) the LayerNorm outputs and the attention output are padded too (orbit2_layernorm_fwd_ld,
+    orbit2_attn_fwd_ld / _bwd_ld): head dimension 128 runs the generated attention kernels, 256 the compiler-scheduled ones"""
     import climate_learn as cl
     from climate_learn import _ops
     from climate_learn.models.hub.components.vit_blocks import Block
     assert _ops._ld_pad(4096) == 4096 + 64 and _ops._ld_pad(12288) == 12288 + 64 and _ops._ld_pad(3072) == 3072
     torch.manual_seed(3)
-    blk = Block(1024, 16, qkv_bias=True, proj_drop=0.1, attn_drop=0.1, drop_path=0.1).cuda().train()
-    x0 = (torch.randn(2, 256, 1024, device="cuda") * 0.5).to(torch.bfloat16)
+    blk = Block(dim, heads, qkv_bias=True, proj_drop=0.1, attn_drop=0.1, drop_path=0.1).cuda().train()
+    x0 = (torch.randn(2, 256, dim, device="cuda") * 0.5).to(torch.bfloat16)
 
     def run(recompute):
         blk.recompute = recompute
