@@ -358,12 +358,13 @@ class BlockFn(torch.autograd.Function):
             _tp.all_reduce_sum(part, grp)
             x1 = _hip.post_reduce(part, M, D, residual=x2d, rowscale=dp1, rows_per_scale=L)
         h2, mean2, rstd2 = _hip.layernorm_fwd(x1, cw(n2w), cw(n2b), out=_rows(M, D, x2d.device))
-        # the hidden tensors (pre, hm, and dpre in backward) carry _ld_pad's row pitch.  `pre` holds what the backward multiplies
+        # the hidden tensors (gsaved, hm, and dpre in backward) carry _ld_pad's row pitch.  `gsaved` (what the GELU layer
+        # saved) holds what the backward multiplies
         # by -- GELU'(pre-activation) x dropout factor, computed in fc1's epilogue where both are in registers (save_dact) --
         # not the pre-activation itself: the fc2 input gradient then has a one-multiply epilogue (4-wave kernel) instead of
         # GELU' + the mask again (reference: autograd of mlp.py:64-65)
-        pre = _rows(M, hid, x2d.device, _gelu_saved_dtype(p_mlp))      # the factor tensor (int16 q14) or the pre-activation
-        hm = _linear_fwd(h2, w1, b1, M, hid, D, pad=True, **_gelu_fwd_kw(pre, p_mlp, s1))
+        gsaved = _rows(M, hid, x2d.device, _gelu_saved_dtype(p_mlp))      # the factor tensor (int16 q14) or the pre-activation
+        hm = _linear_fwd(h2, w1, b1, M, hid, D, pad=True, **_gelu_fwd_kw(gsaved, p_mlp, s1))
         if grp is None:
             x2 = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2, rowscale=dp2, rows_per_scale=L,
                              residual=x1, ldr=D)
@@ -371,7 +372,7 @@ class BlockFn(torch.autograd.Function):
             part = _linear_fwd(hm, w2, b2, M, D, hid, drop_p=p_mlp, seed=s2)
             _tp.all_reduce_sum(part, grp)
             x2 = _hip.post_reduce(part, M, D, residual=x1, rowscale=dp2, rows_per_scale=L)
-        return h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm, x2
+        return h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, gsaved, hm, x2
 
     @staticmethod
     def backward(ctx, dx2):
@@ -381,10 +382,10 @@ class BlockFn(torch.autograd.Function):
         n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2 = ctx.params
         if recompute:
             x2d, dp1, dp2 = ctx.saved_tensors
-            h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm, _ = BlockFn._run(
+            h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, gsaved, hm, _ = BlockFn._run(
                 x2d, B, L, D, H, d, M, hid, ps, sds, dp1, dp2, ctx.params, ctx.grp)
         else:
-            x2d, dp1, dp2, h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, pre, hm = ctx.saved_tensors
+            x2d, dp1, dp2, h1, mean1, rstd1, qkv, o2d, lse, x1, h2, mean2, rstd2, gsaved, hm = ctx.saved_tensors
         grp, Dl = ctx.grp, H * d
         dx2 = dx2.reshape(M, D)
         if dx2.dtype != BF or not dx2.is_contiguous():
@@ -395,10 +396,10 @@ class BlockFn(torch.autograd.Function):
         i2, gb2_ = dws.add(dym2, hm, w2, None if done2 else b2, M, D, hid)
         gb2 = gb2 if done2 else gb2_
         # (fc1's bias gradient = column sums of dpre: the factor-multiply epilogue of this GEMM leaves them per tile row when it can)
-        dpre, dpre_sums = _dx(dym2, w2, M, D, hid, pad=True, want_colsum=_FUSE_COLSUM, **_gelu_bwd_kw(pre, p_mlp, s1)), None
+        dpre, dpre_sums = _dx(dym2, w2, M, D, hid, pad=True, want_colsum=_FUSE_COLSUM, **_gelu_bwd_kw(gsaved, p_mlp, s1)), None
         if _FUSE_COLSUM:
             dpre, dpre_sums = dpre
-        del hm, pre, dym2
+        del hm, gsaved, dym2
         i1, gb1 = dws.add(dpre, h2, w1, b1, M, hid, D, colsum_parts=dpre_sums)
         dh2 = _dx(dpre, w1, M, hid, D)
         del dpre, h2
@@ -456,9 +457,9 @@ class ChainFn(torch.autograd.Function):
                 saved.append(h)
             else:
                 s = seeds.next() if p_mid > 0 else 0
-                pre = torch.empty(M, N, dtype=_gelu_saved_dtype(p_mid), device=x.device)
-                y = _linear_fwd(h, W, b, M, N, K, **_gelu_fwd_kw(pre, p_mid, s))
-                saved += [h, pre]
+                gsaved = torch.empty(M, N, dtype=_gelu_saved_dtype(p_mid), device=x.device)
+                y = _linear_fwd(h, W, b, M, N, K, **_gelu_fwd_kw(gsaved, p_mid, s))
+                saved += [h, gsaved]
             sds.append(s)
             h = y
         ctx.meta = (M, has_ln, p_mid, p_out, sds, lead, D0)
@@ -495,8 +496,8 @@ class ChainFn(torch.autograd.Function):
             else:
                 grads[2 * i], grads[2 * i + 1] = _dw(g, h_in, W, b, M, N, K)
             if i > 0:
-                pre_prev = sv[2 * (i - 1) + 1]
-                g = _dx(g, W, M, N, K, **_gelu_bwd_kw(pre_prev, p_mid, sds[i - 1]))
+                gsaved_prev = sv[2 * (i - 1) + 1]
+                g = _dx(g, W, M, N, K, **_gelu_bwd_kw(gsaved_prev, p_mid, sds[i - 1]))
             elif has_ln or ctx.needs_input_grad[0]:
                 g = _dx(g, W, M, N, K)
         if queued:
