@@ -35,3 +35,29 @@ def test_no_cpu_fallback():
     with pytest.raises(_hip.HipBackendError):
         _hip.layernorm_fwd(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16),
                            torch.zeros(64, dtype=torch.bfloat16))
+
+
+def test_gemm_colsum_dispatch_is_host_logic():
+    """orbit2_gemm_bf16_colsum_rows mirrors the dispatch without touching the GPU: M / 256 rows for the factor-multiply input gradient
+    on whole tiles that fill the chip (the only call that fills colsum_ws), 0 otherwise -- and a call with colsum_ws set that cannot
+    fuse is refused (-3) before anything is launched"""
+    from climate_learn import _hip
+    lib = _hip.lib()
+
+    def args(M, N, K, b_kc=False, mul=True, bias=False, tile=0):
+        a = _hip.GemmArgs()
+        a.A, a.B, a.C = 0x10000, 0x20000, 0x30000            # never dereferenced on the host
+        a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, K, (K if b_kc else N), N
+        a.a_kc, a.b_kc = 1, int(b_kc)
+        a.mul = 0x40000 if mul else None
+        a.bias = 0x50000 if bias else None
+        a.tile_hint = tile
+        return a
+
+    assert lib.orbit2_gemm_bf16_colsum_rows(ctypes.byref(args(131072, 12288, 3072))) == 512      # fc2's input gradient, batch 16
+    assert lib.orbit2_gemm_bf16_colsum_rows(ctypes.byref(args(768, 512, 192, tile=260))) == 3
+    for bad in (args(768, 512, 192), args(131072, 12288, 3072, b_kc=True), args(131072, 12288, 3072, mul=False),
+                args(131072, 12288, 3072, bias=True), args(131072, 12288, 3072, tile=256), args(131000, 12288, 3072)):
+        assert lib.orbit2_gemm_bf16_colsum_rows(ctypes.byref(bad)) == 0
+        bad.colsum_ws = 0x60000
+        assert lib.orbit2_gemm_bf16(ctypes.byref(bad), None) == -3
