@@ -530,6 +530,37 @@ class Emu:
     def op_v_mul_f32(self, w, ops, mods):
         self._fop(w, "v_mul_f32", ops, lambda a, b: a * b)
 
+    def op_v_pk_add_f32(self, w, ops, mods):
+        """packed fp32: d[0:1] = a[0:1] + b[0:1] (register pairs, default op_sel: lo + lo, hi + hi)"""
+        regs = [parse_reg(t) for t in ops[:3]]
+        for r, t in zip(regs, ops[:3]):
+            if not r or r[0] != "v" or r[2] != 2 or r[1] % 2:
+                raise EmuError("v_pk_add_f32: even-aligned v register pairs expected: " + self.cur)
+        if self.strict:
+            self._check_waitstates(w, "v_pk_add_f32", [("v", r[1] + k) for r in regs[1:] for k in range(2)],
+                                   [("v", regs[0][1] + k) for k in range(2)])
+        with np.errstate(all="ignore"):
+            res = [u32(f32(self._src(w, "v%d" % (regs[1][1] + k))) + f32(self._src(w, "v%d" % (regs[2][1] + k)))) for k in range(2)]
+        for k in range(2):
+            self._vset(w, "v%d" % (regs[0][1] + k), res[k])
+
+    def op_v_xor_b32_sdwa(self, w, ops, mods):
+        """dst = sel0(src0) ^ sel1(src1), whole-dword destination (the generators use src1_sel:WORD_1 for x ^ (x >> 16))"""
+        if mods.get("dst_sel", "DWORD") != "DWORD":
+            raise EmuError("v_xor_b32_sdwa: partial destination not modelled: " + self.cur)
+        if self.strict:
+            self._check_waitstates(w, "v_xor_b32_sdwa", self._regs(ops[1:3]), self._regs([ops[0]]))
+        vals = []
+        for k, t in enumerate(ops[1:3]):
+            x = self._src(w, t).astype(np.uint64)
+            sel = mods.get("src%d_sel" % k, "DWORD")
+            if sel.startswith("BYTE_"):
+                x = (x >> (8 * int(sel[5:]))) & 0xFF
+            elif sel.startswith("WORD_"):
+                x = (x >> (16 * int(sel[5:]))) & 0xFFFF
+            vals.append(x)
+        self._vset(w, ops[0], (vals[0] ^ vals[1]).astype(np.uint32))
+
     def op_v_max_f32(self, w, ops, mods):
         self._fop(w, "v_max_f32", ops, lambda a, b: np.fmax(a, b))
 

@@ -113,8 +113,7 @@ def stream_prep(par, slot, half, drop):
 def mix(g, par):
     return ["v_xor_b32 %s, %s, %s" % (V(HM + g), V(RHR[par] + g), V(VKEYH)),
             "v_mul_lo_u32 %s, %s, %s" % (V(HM + g), V(HM + g), S(S_MIX)),
-            "v_lshrrev_b32 %s, 16, %s" % (V(TD), V(HM + g)),
-            "v_xor_b32 %s, %s, %s" % (V(HM + g), V(HM + g), V(TD))]
+            "v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" % (V(HM + g), V(HM + g), V(HM + g))]
 
 
 def stream_gaps(par, drop, g0=4):

@@ -108,8 +108,7 @@ def hashg(blk, khreg, slot):
     hh = HH4[slot]
     return ["v_xor_b32 %s, %s, %s" % (V(hh), V(RH[blk]), V(khreg)),
             "v_mul_lo_u32 %s, %s, %s" % (V(hh), V(hh), S(S_MIX)),
-            "v_lshrrev_b32 %s, 16, %s" % (V(HT), V(hh)),
-            "v_xor_b32 %s, %s, %s" % (V(hh), V(hh), V(HT))]
+            "v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" % (V(hh), V(hh), V(hh))]
 
 
 def stream_gaps(blk, drop, kh, nxt):
