@@ -939,7 +939,8 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
     if (EK == 2) ek.rs_tile = epi.rowscale ? epi.rowscale[m0 / epi.rows_per_scale] : 1.0f;
     if (EK == 1 || EK == 2) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
     const int r8 = tid >> 5, q = tid & 31;
-    constexpr int UNR = EK == 1 ? 4 : 16;              // (2 / 3: short rows, and ld[] must stay in registers)
+    constexpr int UNR = EK == 1 ? 4 : 16;              // (2 / 3: short rows, and ld[] must stay in registers; kind 1 is bound by
+                                                       // vector issue: 1 / 2 / 4 / 8 / 16 rows interleaved are within +-1 %)
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // kind 3 with colsum_ws: this lane's 8 columns over its 32 rows
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
