@@ -477,7 +477,7 @@ def main():
         # Counter traffic (FETCH_SIZE x2 + WRITE_SIZE per launch) from the committed PMC passes of tools/profile_round.sh.  The file
         # is stamped with the library's source hash and the configuration: it is used only for THE SAME build and configuration
         # (a stale file gives null, never a silently wrong number).
-        traffic, traffic_attn, traffic_note, tj = None, None, None, None
+        traffic, traffic_attn, traffic_step, traffic_note, tj = None, None, None, None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
             here = open(_hip.LIB_PATH + ".srchash").read().strip() if os.path.exists(_hip.LIB_PATH + ".srchash") else None
@@ -487,6 +487,7 @@ def main():
                 traffic_note = "profiles/%s was collected on another build of the library (srchash differs)" % TRAFFIC_JSON
             else:
                 traffic = tj["gemm"]["hbm_bytes_per_launch"]
+                traffic_step = tj.get("step", {}).get("hbm_bytes_per_step")
                 traffic_attn = {k: tj[k]["hbm_bytes_per_launch"] for k in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv") if k in tj}
         except Exception as e:
             traffic_note = "no usable profiles/%s (%s)" % (TRAFFIC_JSON, type(e).__name__)
@@ -531,24 +532,32 @@ def main():
                        "activation_recompute": bool(a.recompute),
                        "hipgraph": bool(a.graph),
                        "loss": a.daymet_loss if a.daymet else "bayesian_tv", "in_vars": V},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_split": split,
-                         "algorithmic_bytes_per_launch": gm.get("bytes", None),
-                         "kernel": "orbit2_gemm_bf16 / orbit2_gemm_bf16_grouped (csrc/gemm.hip, hand-written MFMA kernels): "
-                                   "EVERY GEMM of the step -- forward, input gradients, weight gradients -- all launches "
-                                   "of the timed region; no vendor-library GEMM is called",
-                         "traffic_note": traffic_note,
-                         "launches": gm["launches"],
-                         "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
+            # THE STEP against the MFMA peak: FLOPs the kernels of one step EXECUTE (variable aggregation folded, SURVEY 8d: "subtract
+            # the saved FLOPs ... report which formulation was executed"; attention-backward recomputation NOT credited) x samples/s
+            # per GPU.  One "launch" = one step (fwd + loss + bwd + grad all-reduce + loss-scaled AdamW, everything inside the timed
+            # region); traffic = counter bytes of ALL kernels of a step.  The per-family figures follow in roofline_gemm /
+            # roofline_attention; the dense-formulation figure (crediting the folded FLOPs) is context in step_model.
+            "roofline": {"bound": "mfma", "achieved": 3 * f_exec * sps / world / 1e12, "peak": PEAK_BF16 / 1e12,
+                         "unit": "TFLOP/s", "frac": 3 * f_exec * sps / world / PEAK_BF16,
+                         "traffic": traffic_step, "traffic_note": traffic_note,
+                         "algorithmic_flops_per_launch": 3 * f_exec * B,
+                         "kernel": "the whole training step: every kernel of the timed region (csrc/*.hip), executed-FLOP formulation "
+                                   "(folded variable aggregation); one launch = one step of %d samples" % B,
+                         "launches": a.steps, "avg_launch_ms": 1e3 * dt / a.steps},
+            # every GEMM of the step (the family that holds most of its FLOPs), same fields, per kernel launch
+            "roofline_gemm": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                              "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_split": split,
+                              "algorithmic_bytes_per_launch": gm.get("bytes", None),
+                              "kernel": "orbit2_gemm_bf16 / orbit2_gemm_bf16_grouped (csrc/gemm.hip, hand-written MFMA kernels): "
+                                        "EVERY GEMM of the step -- forward, input gradients, weight gradients -- all launches "
+                                        "of the timed region; no vendor-library GEMM is called",
+                              "traffic_note": traffic_note,
+                              "launches": gm["launches"],
+                              "avg_launch_ms": gm["ms"] / max(1, gm["launches"])},
             # the family FURTHEST below its roofline, with the same fields: forward and backward launches of the
             # flash-attention kernels (csrc/attn.hip); algorithmic FLOPs 4 B H L^2 d forward, 8 B H L^2 d backward (the backward's
             # recomputation of S and its two-kernel split are NOT credited)
             "roofline_attention": _attn_roofline(prof, traffic_attn, traffic_note),
-            # the whole step against the same peak: FLOPs the kernels execute (folded variable aggregation) / wall time
-            "roofline_step": {"bound": "mfma", "achieved": 3 * f_exec * sps / world / 1e12, "peak": PEAK_BF16 / 1e12,
-                              "unit": "TFLOP/s", "frac": 3 * f_exec * sps / world / PEAK_BF16,
-                              "note": "executed-FLOP fraction of the step (fwd + loss + bwd + all-reduce + AdamW inside the timed "
-                                      "region); dense-formulation figure in step_model"},
             "step_model": {
                 "model_flops_per_sample_dense": 3 * f_dense, "executed_flops_per_sample_folded_varagg": 3 * f_exec,
                 "mfma_frac_of_peak_dense_formulation": 3 * f_dense * sps / world / PEAK_BF16,

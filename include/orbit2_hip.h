@@ -6,10 +6,17 @@
  * interface (file:line, relative to /root/reference) whose arithmetic it replaces.
  *
  * Conventions: every pointer is caller-owned DEVICE memory, row-major contiguous
- * unless a leading dimension is given; bf16 tensors are raw uint16; no allocation, no sync, no
- * global mutable state inside; asynchronous on `stream` (a hipStream_t passed as void*);
- * returns 0 on success, <0 on error (never throws).  RNG = counter-based hash of (seed, element
- * index) -- the caller advances `seed` per call site and per step.
+ * unless a leading dimension is given; bf16 tensors are raw uint16; no allocation, no sync;
+ * asynchronous on `stream` (a hipStream_t passed as void*); returns 0 on success, <0 on error
+ * (never throws).  RNG = counter-based hash of (seed, element index) -- the caller advances
+ * `seed` per call site and per step.
+ *
+ * State: the library keeps NO host-side mutable state and exactly ONE piece of device-side
+ * mutable state, the 64-bit seed salt written by orbit2_seed_salt() (see there): one value per
+ * device per process, 0 unless set, read by every seeded kernel on every stream.  Everything else
+ * a call touches is passed in.  Calls are re-entrant across streams and threads as long as no
+ * call that WRITES the salt is in flight concurrently with seeded kernels of another stream whose
+ * forward and backward must agree (the salt is read at kernel run time, not at launch).
  */
 #ifndef ORBIT2_HIP_H
 #define ORBIT2_HIP_H
@@ -268,10 +275,18 @@ int orbit2_adamw(float* p, float* m, float* v, const void* g, int g_fp32, void* 
 /* found_inf[0] = 1 if any element is inf/nan (never cleared here) */
 int orbit2_check_finite(const void* g, int g_fp32, int64_t n, float* found_inf, void* stream);
 
-/* Device-side seed salt: every seeded kernel (GEMM-epilogue dropout, attention dropout, dropout backward, DropPath
- * scales) xors it into the seed argument.  add = 0 sets it, add = 1 advances it by `value`; stream-ordered (a one-thread
- * kernel per library module).  0 by default, i.e. the seeds are used as passed.  Purpose: a training step captured in a
- * hipGraph begins with orbit2_seed_salt(odd constant, 1, stream), so each replay draws new masks. */
+/* Device-side seed salt -- the library's only device-global mutable state: every seeded kernel (GEMM-epilogue dropout,
+ * attention dropout, dropout backward, DropPath scales) xors it into the seed argument.  add = 0 sets it, add = 1 advances it
+ * by `value`; stream-ordered (a one-thread kernel per library module).  0 by default, i.e. the seeds are used as passed.
+ * Purpose: a training step captured in a hipGraph begins with orbit2_seed_salt(odd constant, 1, stream), so each replay draws
+ * new masks (seeds are kernel arguments, frozen at capture).
+ * Consequences of it being per device and not per engine: (1) the salt must not change between a step's forward and the
+ * backward that regenerates its masks -- within one stream the stream order guarantees it; two engines stepping CONCURRENTLY on
+ * different streams of one device must not both use salted (graph-captured) steps; (2) engines that take turns on one device
+ * share the counter: each one's mask sequence then depends on how many replays the others ran (still fresh masks every step,
+ * still forward/backward-consistent, but not reproducible per engine); (3) eager steps that follow replays see the salt the
+ * last replay left (set it back with add = 0 when bit-reproducing an eager run).  One process per GPU with one training
+ * engine -- the reference's layout (examples/intermediate_downscaling.py:161-262) -- meets none of these cases. */
 int orbit2_seed_salt(uint64_t value, int add, void* stream);
 
 /* hardware self-test of the MFMA / LDS-transpose / LDS-DMA layouts the kernels assume; returns a

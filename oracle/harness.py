@@ -8,16 +8,14 @@ import numpy as np
 import torch
 
 
-def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_vars=("total_precipitation_24hr",),
-               in_vars=None):
-    """(HIP model on cuda, oracle state dict + config on CPU) holding identical weights + a seeded batch.
-    in_vars: the input variable list (default: the four constants + the output variables)."""
+def oracle_case(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_vars=("total_precipitation_24hr",),
+                in_vars=None):
+    """the CPU side of a seeded case: oracle config + state dict + batch.  Imports nothing of the product package, so
+    tests/golden/make_golden_bf16_spread.py can rebuild the very same case beside the reference's modules."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for p in (root, os.path.join(root, "orbit-2_amd")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    if root not in sys.path:
+        sys.path.insert(0, root)
     from oracle import orbit2_oracle as O
-    from climate_learn.models.hub import Res_Slim_ViT
     consts = ["land_sea_mask", "orography", "lattitude", "landcover"]
     in_vars = list(in_vars) if in_vars is not None else consts + [v for v in out_vars]
     cfg = O.Config(in_vars, grid, len(out_vars), D, depth, dd, heads, spatial_resolution=156.0)
@@ -28,15 +26,77 @@ def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_va
     for k in sd:
         if k.endswith(".bias") and "norm" not in k:
             sd[k] = 0.05 * torch.randn(sd[k].shape, generator=g)
-    model = Res_Slim_ViT(in_vars, grid, len(in_vars), len(out_vars), 1, patch_size=2, embed_dim=D, depth=depth,
-                         decoder_depth=dd, num_heads=heads, drop_path=0.0, drop_rate=0.0, learn_pos_emb=True)
-    model.load_state_dict(sd, strict=True)
-    model.data_config(156.0, grid, len(in_vars), len(out_vars))
     x = torch.randn(B, len(in_vars), *grid, generator=g)
     y = torch.randn(B, len(out_vars), grid[0] * 4 + 1, grid[1] * 4 + 3, generator=g)
     pi = list(out_vars).index("total_precipitation_24hr")
     y[:, pi] = torch.log1p(torch.relu(y[:, pi]))
-    return model, sd, cfg, O, x, y, in_vars, list(out_vars)
+    return sd, cfg, O, x, y, in_vars, list(out_vars)
+
+
+def build_pair(D=128, depth=1, heads=2, dd=1, grid=(16, 32), B=2, seed=0, out_vars=("total_precipitation_24hr",),
+               in_vars=None):
+    """(HIP model on cuda, oracle state dict + config on CPU) holding identical weights + a seeded batch.
+    in_vars: the input variable list (default: the four constants + the output variables)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "orbit-2_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from climate_learn.models.hub import Res_Slim_ViT
+    sd, cfg, O, x, y, in_vars, out_vars = oracle_case(D, depth, heads, dd, grid, B, seed, out_vars, in_vars)
+    model = Res_Slim_ViT(in_vars, grid, len(in_vars), len(out_vars), 1, patch_size=2, embed_dim=D, depth=depth,
+                         decoder_depth=dd, num_heads=heads, drop_path=0.0, drop_rate=0.0, learn_pos_emb=True)
+    model.load_state_dict(sd, strict=True)
+    model.data_config(156.0, grid, len(in_vars), len(out_vars))
+    return model, sd, cfg, O, x, y, in_vars, out_vars
+
+
+# Seeded cases whose bf16 spread was measured on the REFERENCE's own model (tests/golden/bf16_spread_configs.npz, written by
+# tests/golden/make_golden_bf16_spread.py from these very arguments): smoke() and the whole-model tests at these shapes take
+# their tolerance from that file, not from anything computed at test time.
+ERA5_CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
+ERA5_VARS = ERA5_CONST + [
+    "2m_temperature", "2m_temperature_max", "2m_temperature_min", "temperature_200", "temperature_500",
+    "temperature_850", "10m_u_component_of_wind", "u_component_of_wind_200", "u_component_of_wind_500",
+    "u_component_of_wind_850", "10m_v_component_of_wind", "v_component_of_wind_200", "v_component_of_wind_500",
+    "v_component_of_wind_850", "specific_humidity_200", "specific_humidity_500", "specific_humidity_850",
+    "total_precipitation_24hr", "volumetric_soil_water_layer_1"]
+ERA5_OUT = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
+ERA5_VW = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0}
+PINNED_CASES = {
+    "smoke": dict(),                                                                     # build_pair()'s defaults
+    "interm_117m": dict(D=1024, depth=8, heads=16, dd=4, grid=(32, 64), B=2, seed=11, out_vars=ERA5_OUT, in_vars=ERA5_VARS),
+    "odd_grid": dict(D=128, depth=2, heads=2, grid=(10, 20), B=3, seed=11),
+}
+PINNED_VW = {"smoke": {"total_precipitation_24hr": 1.0}, "interm_117m": ERA5_VW, "odd_grid": {"total_precipitation_24hr": 1.0}}
+
+
+def case_fingerprint(sd, x, y):
+    """a few float64 sums that identify a seeded case (weights + batch): stored beside the committed spreads, compared by
+    the tests before they use them"""
+    keys = sorted(sd)
+    return np.array([float(x.double().sum()), float(y.double().abs().sum()), float(sd[keys[0]].double().abs().sum()),
+                     float(sd[keys[-1]].double().abs().sum()), float(sum(v.numel() for v in sd.values()))])
+
+
+def reference_spread(name, sd=None, x=None, y=None):
+    """{param: normalised max error of the REFERENCE's bf16 gradient against its fp32 gradient} + 'l2.'+param, 'pred', 'loss'
+    for a PINNED_CASES entry, read from the committed fixture.  With sd/x/y given, first checks the fixture was written for
+    exactly this case."""
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                             "bf16_spread_configs.npz"))
+    if sd is not None:
+        fp = case_fingerprint(sd, x, y)
+        assert np.allclose(fp, z[name + "/fingerprint"], rtol=1e-9, atol=1e-9), \
+            "bf16_spread_configs.npz was written for another '%s' case: regenerate it (tests/golden/make_golden_bf16_spread.py)" % name
+    out = {}
+    for k in z.files:
+        if k.startswith(name + "/g."):
+            out[k[len(name) + 3:]] = float(z[k])
+        elif k.startswith(name + "/l2."):
+            out["l2." + k[len(name) + 4:]] = float(z[k])
+        elif k in (name + "/pred", name + "/loss"):
+            out[k[len(name) + 1:]] = float(z[k])
+    return out
 
 
 def nerr(a, b):
@@ -44,15 +104,21 @@ def nerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
 
 
-TOL_FLOOR, TOL_FACTOR = 2e-2, 1.5
+TOL_FLOOR, TOL_FACTOR, TOL_CEILING = 2e-2, 1.5, 0.15
 
 
-def grad_tolerance(spread):
+def grad_tolerance(spread, name=None):
     """the tolerance contract: a HIP result may differ from the fp32 oracle by the contract's 2e-2 (normalised max
-    error) or by 1.5 x what running the SAME math in plain bf16 moves that tensor, whichever is larger.  `spread` is that
-    measured bf16-vs-fp32 figure: the reference's own (tests/golden/bf16_spread.npz, written from the reference's modules by
-    tests/golden/make_golden_bf16_spread.py) where a fixture exists, the oracle's (oracle_bf16_spread) elsewhere."""
-    return max(TOL_FLOOR, TOL_FACTOR * float(spread))
+    error) or by 1.5 x what running the SAME math in plain bf16 moves that tensor, whichever is larger -- and never by more
+    than TOL_CEILING, however noisy the tensor.  `spread` is that measured bf16-vs-fp32 figure: the REFERENCE's own wherever
+    a fixture exists (tests/golden/bf16_spread.npz for the reference-golden cases, bf16_spread_configs.npz = `reference_spread`
+    for smoke / interm_117m / the odd grid; both written from the reference's modules by make_golden_bf16_spread.py); the
+    oracle's (oracle_bf16_spread) only where the reference cannot produce one: train-mode masks (its RNG streams are not
+    ours) and the LPIPS loss (the package is absent).  A tolerance above the 2e-2 floor is printed when `name` is given."""
+    tol = min(max(TOL_FLOOR, TOL_FACTOR * float(spread)), TOL_CEILING)
+    if name is not None and tol > TOL_FLOOR:
+        print("[tolerance] %s: bf16 spread %.2e -> %.2e (> %.0e floor)" % (name, float(spread), tol, TOL_FLOOR), flush=True)
+    return tol
 
 
 def oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, loss="bayesian_tv", vw=None, fp32_grads=None, **kw):
@@ -100,14 +166,14 @@ def smoke_step():
     sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
     ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw)
     ref.backward()
-    e_loss = abs(float(loss) - float(ref)) / abs(float(ref))
+    e_loss = abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach()))
     e_g = nerr(model.head[0].weight.grad, sdo["head.0.weight"].grad)
     e_q = nerr(model.blocks[0].attn.qkv.weight.grad, sdo["blocks.0.attn.qkv.weight"].grad)
-    # tolerance per tensor: 2e-2, or 1.5 x what plain bf16 arithmetic moves this tensor of this very model (measured here)
-    sp = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw,
-                            fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
+    # tolerance per tensor: 2e-2, or 1.5 x what bf16 arithmetic moves this tensor in the REFERENCE's own model on this very case
+    # (committed: tests/golden/bf16_spread_configs.npz, entry "smoke"); nothing is measured here
+    sp = reference_spread("smoke", sd, x, y)
     t_g, t_q = grad_tolerance(sp["head.0.weight"]), grad_tolerance(sp["blocks.0.attn.qkv.weight"])
-    print("[smoke] loss hip=%.6f oracle=%.6f rel=%.2e | grad err head.0=%.2e (bf16 spread %.2e, tol %.2e) qkv=%.2e "
-          "(bf16 spread %.2e, tol %.2e)" % (float(loss), float(ref), e_loss, e_g, sp["head.0.weight"], t_g, e_q,
-                                            sp["blocks.0.attn.qkv.weight"], t_q), flush=True)
+    print("[smoke] loss hip=%.6f oracle=%.6f rel=%.2e | grad err head.0=%.2e (reference bf16 spread %.2e, tol %.2e) qkv=%.2e "
+          "(reference bf16 spread %.2e, tol %.2e)" % (float(loss), float(ref), e_loss, e_g, sp["head.0.weight"], t_g, e_q,
+                                                      sp["blocks.0.attn.qkv.weight"], t_q), flush=True)
     assert e_loss < 2e-2 and e_g <= t_g and e_q <= t_q, "HIP step disagrees with the CPU oracle"

@@ -22,6 +22,31 @@ from .trainer import training_step
 
 SALT_STEP = 0x9E3779B97F4A7C15       # odd: the salt walks through all 2^64 values
 
+# Capture mode.  Under the runtime's default ("global") ANY thread of the process that makes a capture-unsafe HIP call while a
+# capture is open invalidates the capture -- and the call itself fails.  A process that has an RCCL process group has such a
+# thread: ProcessGroupNCCL's watchdog polls hipEventQuery on the end events of every collective it still tracks (the warm-up
+# passes' bucket all-reduces); when its query lands inside a global-mode capture it gets hipErrorStreamCaptureUnsupported, throws
+# from a non-Python thread, and the process ends in std::terminate -> SIGABRT (round 4's driver run).  Whether it lands
+# there is a race against its 100 ms poll.  "thread_local" restricts the check to the capturing thread.  That is safe for this
+# body because everything the capture must not see is already excluded by construction: every kernel of the step is launched
+# from THIS thread on the capturing stream or on the engine's communication stream forked from it by an event recorded inside
+# the capture; no other thread of ours launches work, allocates or synchronises (the data loader threads only touch host memory
+# and pinned buffers); the allocator's own hipMalloc inside a capture is already wrapped in a relaxed-mode guard by PyTorch;
+# and the watchdog's event queries concern streams' PAST work, which a capture does not reorder.
+CAPTURE_ERROR_MODE = "thread_local"
+
+
+def _quiesce_collectives(device):
+    """Host-synchronises the device and gives the process-group watchdog time to retire every collective it tracks, so that no
+    event of an uncaptured collective is still being polled when the capture opens (belt to CAPTURE_ERROR_MODE's braces: with the
+    work list empty the watchdog makes no HIP call at all)."""
+    import time
+    import torch.distributed as dist
+    torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "gloo":
+        time.sleep(0.35)                             # > 3 watchdog polls (kWatchdogThreadSleepMillis = 100)
+        torch.cuda.synchronize(device)
+
 
 class GraphedTrainStep:
     def __init__(self, engine, loss_metric, batch, var_weights, scaler=None, warmup: int = 2):
@@ -67,8 +92,9 @@ class GraphedTrainStep:
             for _ in range(self.warmup):
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
+        _quiesce_collectives(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
             self.loss = self._body()
         self.captures += 1
 

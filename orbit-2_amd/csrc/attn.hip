@@ -526,9 +526,16 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
 // is placed by the generator (its header describes the schedule); tools/cdna_emu.py executes the same text on the CPU
 // (tests/test_attn_asm_emu_cpu.py).  What the compiler contributes: the workgroup's coordinates, the key-group hash table of the
 // sequence (LDS, read by the dropout mask) and the lane's two row hashes.
-// Contract audited by tests/test_attn_asm_audit_cpu.py: no scratch, no spills, the statement's registers (v8-v255, a0-a255,
+// Contract audited by tests/test_w4_audit_cpu.py: no scratch, no spills, the statement's registers (v8-v255, a0-a255,
 // s36-s69) are clobbers so the descriptor allocates 512 registers per lane.
 #define O2_AF_MAX_L 16384
+// The generated streams address K / V tiles, query rows and output rows with 32-bit BYTE offsets from per-(sample, head) base
+// pointers (strideb = pitch * 2; offsets up to L * pitch * 2): the launchers take the generated kernels only when those offsets
+// stay below 2^31 and fall back to the compiler-scheduled kernels (64-bit addressing) otherwise.
+static inline bool attn_w4_range_ok(int L, int ldq, int ldo) {
+  const uint64_t lim = 1ull << 31;
+  return (uint64_t)(L + 64) * (uint64_t)ldq * 2ull < lim && (uint64_t)(L + 64) * (uint64_t)ldo * 2ull < lim;
+}
 template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int L, int H, unsigned thr, float dscale,
@@ -1608,7 +1615,8 @@ extern "C" int orbit2_attn_fwd_ld(const void* qkv, void* out, float* lse, int B,
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   const float dscale = 256.0f / (256.0f - (float)thr);
   hipStream_t s = (hipStream_t)stream;
-  if (d == 128 && (flags & ORBIT2_ATTN_Q_PRESCALED) && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L) {
+  if (d == 128 && (flags & ORBIT2_ATTN_Q_PRESCALED) && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L &&
+      attn_w4_range_ok(L, ldq, ldo)) {
     dim3 grid((unsigned)((L / 256) * H * B)), block(256);
     if (thr) hipLaunchKernelGGL((attn_fwd_w4_kernel<true>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed, ldo, ldq);
     else hipLaunchKernelGGL((attn_fwd_w4_kernel<false>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, thr, dscale, seed, ldo, ldq);
@@ -1636,7 +1644,8 @@ static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, co
   dim3 grid(((L + NW * 32 - 1) / (NW * 32)) * H * B), block(NW * 64);
   const bool pre = (flags & ORBIT2_ATTN_Q_PRESCALED) != 0;
   const float opmul = pre ? 1.0f : scale * 1.4426950408889634f, kgrad = pre ? 0.6931471805599453f : scale;
-  if (DV == 128 && pre && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L) {
+  const bool w4_range = attn_w4_range_ok(L, ldq, ldq);     // (dO / dqkv rows are no wider than the qkv pitch)
+  if (DV == 128 && pre && !(flags & ORBIT2_ATTN_NO_W4) && L % 256 == 0 && L <= O2_AF_MAX_L && w4_range) {
     // the generated one-wave-per-SIMD dQ kernel (256-row workgroups whatever NW is)
     hipLaunchKernelGGL((attn_bwd_dq_w4_kernel<DR>), dim3((unsigned)((L / 256) * H * B)), dim3(256), 0, s, q_, do_, lse, delta, dq_,
                        L, H, thr, DR ? scale * dscale : scale, seed, Lp, ldq);
@@ -1645,7 +1654,7 @@ static void launch_bwd(const bf16_t* q_, const bf16_t* do_, const float* lse, co
                        seed, opmul, Lp, ldq);
   }
   if (DV == 128 && pre && !(flags & (ORBIT2_ATTN_NO_W4 | ORBIT2_ATTN_SPLIT_DKV)) && L % 256 == 0 && L <= O2_AF_MAX_L &&
-      (uint64_t)B * (uint64_t)H * (uint64_t)L < (1ull << 32)) {
+      (uint64_t)B * (uint64_t)H * (uint64_t)L < (1ull << 32) && w4_range) {
     // the generated one-wave-per-SIMD dK + dV kernel: 128 keys per workgroup
     hipLaunchKernelGGL((attn_bwd_dkv_w4_kernel<DR>), dim3((unsigned)((L / 128) * H * B)), dim3(256), 0, s, q_, do_, lse, delta, dq_,
                        L, H, thr, DR ? kgrad * dscale : kgrad, DR ? dscale : 1.0f, seed, Lp, ldq);

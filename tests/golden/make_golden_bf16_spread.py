@@ -10,6 +10,9 @@ per case: normalised max error (max |a - b| / max |b|) and relative L2 error of 
 bf16 run against fp32 run -> tests/golden/bf16_spread.npz.  tests/test_model_gpu.py / test_configs_gpu.py / oracle/harness.py
 hold the HIP path to max(2e-2, 1.5 x this spread) per tensor.
 
+The seeded cases without a reference-golden fixture (smoke, interm_117m, the odd grid) are measured the same way by
+`config_cases` -> tests/golden/bf16_spread_configs.npz.
+
 Runs ONLY in the build container (where /root/reference exists); numbers only are stored.
 Usage:  python tests/golden/make_golden_bf16_spread.py
 """
@@ -107,6 +110,73 @@ def main():
                ", ".join("%s %.2e" % (k.split("/g.")[1], v) for v, k in gs[:6])), flush=True)
     np.savez_compressed(os.path.join(HERE, "bf16_spread.npz"), **out)
     print("wrote bf16_spread.npz with %d entries" % len(out))
+    config_cases(rs, fn, FusedAttn)
+
+
+def config_cases(rs, fn, FusedAttn):
+    """The same measurement for the seeded cases that have no reference-golden fixture because their weights come from the
+    oracle's initialiser (oracle/harness.py: PINNED_CASES -- smoke(), BASELINE configs[1] interm_117m at its real
+    architecture, the odd 10 x 20 grid): the case is rebuilt here from the same arguments, its weights are loaded into the
+    REFERENCE's Res_Slim_ViT, which is run in fp32 and in bf16.  Two things come out of it:
+      * the oracle itself is pinned at those shapes (reference fp32 prediction / loss / every gradient against the oracle's,
+        asserted below at 1e-4 / 1e-5 / 2e-3);
+      * bf16_spread_configs.npz: per case the reference's bf16-vs-fp32 spread of the prediction, the loss and every
+        gradient (normalised max error and relative L2) + a fingerprint of the case."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import harness as H
+    out = {}
+    for name, kw in H.PINNED_CASES.items():
+        sd, cfg, O, x, y, in_vars, out_vars = H.oracle_case(**kw)
+        vw = H.PINNED_VW[name]
+        Vn, C = len(in_vars), len(out_vars)
+        pi = out_vars.index("total_precipitation_24hr")
+        res = {}
+        for mode in ("fp32", "bf16"):
+            torch.manual_seed(0)
+            model = rs.Res_Slim_ViT(in_vars, cfg.img_size, Vn, C, history=1, superres_mag=4, cnn_ratio=4, patch_size=2,
+                                    drop_path=0.0, drop_rate=0.0, learn_pos_emb=True, embed_dim=cfg.embed_dim, depth=cfg.depth,
+                                    decoder_depth=cfg.decoder_depth, num_heads=cfg.num_heads, mlp_ratio=4,
+                                    FusedAttn_option=FusedAttn.NONE if mode == "fp32" else FusedAttn.DEFAULT)
+            model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+            model.data_config(156.0, cfg.img_size, Vn, C)
+            model.eval()
+            xin = x
+            if mode == "bf16":
+                model = model.bfloat16()
+                xin = x.bfloat16()
+            pred = model(xin, in_vars, out_vars).float()
+            yhat = pred.clone()
+            yhat[:, pi] = torch.clamp(pred[:, pi], min=0.0)
+            yc = y[:, :, : yhat.shape[2], : yhat.shape[3]]
+            loss = fn.bayesian_tv(yhat, yc, out_vars, vw, False)[-1]
+            loss.backward()
+            res[mode] = (pred.detach(), float(loss), {n: p.grad.detach().float() for n, p in model.named_parameters() if p.grad is not None})
+        # pin: the oracle on the same case
+        sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        opred = O.forward(sdo, cfg, x, in_vars, out_vars)
+        oloss = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw)
+        oloss.backward()
+        e_pred = nerr(opred, res["fp32"][0])
+        e_loss = abs(float(oloss) - res["fp32"][1]) / abs(res["fp32"][1])
+        e_grad = {n: nerr(sdo[n].grad, g) for n, g in res["fp32"][2].items()}
+        worst = max(e_grad.items(), key=lambda kv: kv[1])
+        print("%s: oracle vs reference fp32: pred %.1e loss %.1e worst gradient %s %.1e (%d tensors)"
+              % (name, e_pred, e_loss, worst[0], worst[1], len(e_grad)), flush=True)
+        assert e_pred < 1e-4 and e_loss < 1e-5 and worst[1] < 2e-3, name
+        assert set(e_grad) == {k for k, v in sdo.items() if v.grad is not None}, name
+        out["%s/fingerprint" % name] = H.case_fingerprint(sd, x, y)
+        out["%s/oracle_vs_reference_fp32" % name] = np.array([e_pred, e_loss, worst[1]])
+        out["%s/pred" % name] = np.float64(nerr(res["bf16"][0], res["fp32"][0]))
+        out["%s/loss" % name] = np.float64(abs(res["bf16"][1] - res["fp32"][1]) / abs(res["fp32"][1]))
+        for n, g32 in res["fp32"][2].items():
+            out["%s/g.%s" % (name, n)] = np.float64(nerr(res["bf16"][2][n], g32))
+            out["%s/l2.%s" % (name, n)] = np.float64(rel_l2(res["bf16"][2][n], g32))
+        gs = sorted(((v, k) for k, v in out.items() if k.startswith(name + "/g.")), reverse=True)
+        print("%s: reference bf16 vs fp32: pred %.2e loss %.2e | gradients: median %.2e, worst %s" %
+              (name, out[name + "/pred"], out[name + "/loss"], float(np.median([v for v, _ in gs])),
+               ", ".join("%s %.2e" % (k.split("/g.")[1], v) for v, k in gs[:6])), flush=True)
+    np.savez_compressed(os.path.join(HERE, "bf16_spread_configs.npz"), **out)
+    print("wrote bf16_spread_configs.npz with %d entries" % len(out))
 
 
 if __name__ == "__main__":

@@ -36,13 +36,15 @@ def rel_l2(a, b):
 def test_interm_117m_whole_model_forward_backward_vs_oracle():
     """BASELINE configs[1] at its real architecture and grid (2 of the 8 samples of the YAML batch: the oracle runs them
     on the CPU in seconds): prediction <= 2e-2, loss <= 1e-2, every parameter gradient within max(2e-2, 1.5 x the bf16 spread of
-    that tensor) in normalised max error AND relative L2 -- the spread measured here by running the oracle once more in plain
-    bf16 on the same weights and inputs (oracle/harness.py: no reference fixture exists at this size)"""
+    that tensor, capped at 0.15) in normalised max error AND relative L2 -- the spread being the REFERENCE model's own bf16-vs-fp32
+    movement on this very case (weights, inputs), committed as tests/golden/bf16_spread_configs.npz entry "interm_117m" by
+    tests/golden/make_golden_bf16_spread.py, which also pins the oracle to the reference at this architecture (prediction 8e-8,
+    gradients <= 1.5e-6).  Nothing about the tolerance is measured at test time."""
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.trainer import training_step
-    from oracle.harness import build_pair
-    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=1024, depth=8, heads=16, dd=4, grid=(32, 64), B=2, seed=11,
-                                                            out_vars=OUT_VARS, in_vars=ERA5_VARS)
+    from oracle.harness import PINNED_CASES, build_pair
+    assert PINNED_CASES["interm_117m"]["in_vars"] == ERA5_VARS and PINNED_CASES["interm_117m"]["out_vars"] == OUT_VARS
+    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(**PINNED_CASES["interm_117m"])
     n = sum(p.numel() for p in model.parameters())
     assert 1.09e8 < n < 1.12e8 and len(in_vars) == 23            # 110 035 331 in the reference (SURVEY 6)
     dev = torch.device("cuda")
@@ -65,13 +67,18 @@ def test_interm_117m_whole_model_forward_backward_vs_oracle():
             continue
         assert p.grad is not None, name
         worst[name], l2[name] = nerr(p.grad, g), rel_l2(p.grad, g)
-    from oracle.harness import grad_tolerance, oracle_bf16_spread
-    sp = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", VW,
-                            fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
+    from oracle.harness import grad_tolerance, reference_spread
+    sp = reference_spread("interm_117m", sd, x, y)
+    assert nerr(pred, pref) < max(2e-2, 1.5 * sp["pred"])
     print(sorted(((round(e, 4), round(sp[k], 4), k) for k, e in worst.items()), reverse=True)[:10])
     bad = {k: (e, sp[k], l2[k], sp["l2." + k]) for k, e in worst.items()
-           if e > grad_tolerance(sp[k]) or l2[k] > grad_tolerance(sp["l2." + k])}
+           if e > grad_tolerance(sp[k], k) or l2[k] > grad_tolerance(sp["l2." + k])}
     assert len(worst) > 120 and not bad, bad
+    # beside the per-tensor bounds, the whole gradient: relative L2 over all parameters together
+    num = sum(float((p.grad.detach().float().cpu().double() - sdo[n].grad.double()).pow(2).sum()) for n, p in model.named_parameters()
+              if sdo[n].grad is not None)
+    den = sum(float(sdo[n].grad.double().pow(2).sum()) for n, p in model.named_parameters() if sdo[n].grad is not None)
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
 
 
 def test_interm_10b_training_step_with_recompute():

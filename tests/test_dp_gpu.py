@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests._child import run_child
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -87,7 +89,7 @@ def _worker(rank, world, port, shard, q):
                 assert float((v - ref_sd[k].cpu()).abs().max()) <= 2.01e-3, k
         q.put((rank, "ok"))
     except Exception:
-        q.put((rank, traceback.format_exc()))
+        q.put((rank, "fail", traceback.format_exc()))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -95,20 +97,15 @@ def _worker(rank, world, port, shard, q):
 
 @pytest.mark.parametrize("shard", [False, True], ids=["all_reduce", "sharded_optimizer"])
 def test_two_ranks_equal_one_rank_with_the_whole_batch(shard):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, shard, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(60)
-    for r in res:
-        assert r[1] == "ok", "rank %d:\n%s" % (r[0], r[1])
+    from tests._child import spawn_ranks
+    spawn_ranks(_worker, 2, shard, timeout=600)
 
 
-def test_fully_sharded_engine_matches_replicated_engine(golden_dir, monkeypatch):
+def test_fully_sharded_engine_matches_replicated_engine(golden_dir):
+    run_child(__file__, "child_fully_sharded_engine_matches_replicated_engine", golden_dir)
+
+
+def child_fully_sharded_engine_matches_replicated_engine(golden_dir):
     """SURVEY 8f-4 (reference FSDP FULL_SHARD, examples/intermediate_downscaling.py:609-617) on the GPU with the collectives
     forced on over a single-rank RCCL group: units gathered one ahead on the communication stream, gradients
     reduce-scattered from pooled buffers, AdamW on the chunks.  After ONE step the parameters of every Block and of the head
@@ -121,9 +118,7 @@ def test_fully_sharded_engine_matches_replicated_engine(golden_dir, monkeypatch)
     from climate_learn.models.hub.components.vit_blocks import Block
     from climate_learn.trainer import training_step
     from tests.test_model_gpu import load, VW
-    monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
-    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29657")
+    os.environ.update(ORBIT2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))

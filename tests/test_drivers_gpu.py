@@ -10,12 +10,14 @@ import pytest
 import torch
 import yaml
 
+from tests._child import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(script, cfg, cwd):
-    env = dict(os.environ, MASTER_PORT="29611")
+    env = dict(os.environ, MASTER_PORT=str(free_port()))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script), cfg], cwd=cwd, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -215,9 +217,9 @@ def test_training_driver_tensor_parallel_two_ranks_one_card(tmp_path, ddp):
     yaml.safe_dump(conf, open(cfg, "w"))
 
     def run_pair():
-        procs = []
+        procs, port = [], str(free_port())
         for r in range(world):
-            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE=str(world), RANK=str(r),
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world), RANK=str(r),
                        LOCAL_RANK="0", ORBIT2_DIST_BACKEND="gloo")
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "intermediate_downscaling.py"), cfg],
                                           cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -265,9 +267,9 @@ def test_training_driver_two_data_parallel_ranks_one_card(tmp_path, mode):
     conf["data"]["synthetic"]["ERA5_1"].update(steps_per_epoch=3)
     cfg = os.path.join(tmp_path, "dp.yaml")
     yaml.safe_dump(conf, open(cfg, "w"))
-    procs = []
+    procs, port = [], str(free_port())
     for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29644", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0",
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0",
                    ORBIT2_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "intermediate_downscaling.py"), cfg],
                                       cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -289,9 +291,9 @@ def test_bench_contract_two_ranks_one_card(tmp_path):
     import json
 
     def run(extra):
-        procs = []
+        procs, port = [], str(free_port())
         for r in range(2):
-            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0",
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0",
                        ORBIT2_DIST_BACKEND="gloo")
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
                                            "--warmup", "1", "--model", "interm_8m", "--grid", "32x64", "--batch", "2",
@@ -311,7 +313,7 @@ def test_bench_contract_two_ranks_one_card(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job samples / max-rank time
-    assert d["roofline"]["launches"] > 0
+    assert d["roofline"]["launches"] == 3 and d["roofline_gemm"]["launches"] > 0
     # communication accounting of the timed region: did the bucket collectives hide behind backward?
     c = d["comm"]
     assert d["comm_ms_per_step"] == c["comm_ms_per_step"] > 0 and d["exposed_comm_ms"] == c["exposed_comm_ms_per_step"] >= 0
@@ -319,7 +321,7 @@ def test_bench_contract_two_ranks_one_card(tmp_path):
     nparam = d["config"]["params"]
     assert 2 * nparam <= c["comm_bytes_per_step"] <= 4.5 * nparam      # bf16 buckets + the fp32 ranges of the fp32-compute parameters
     assert d["roofline_attention"]["launches"] > 0 and 0 < d["roofline_attention"]["frac"] < 1
-    assert 0 < d["roofline_step"]["frac"] < 1
+    assert 0 < d["roofline"]["frac"] < 1 and "roofline_step" not in d      # `roofline` IS the step's executed-FLOP figure
     f = run(["--fsdp"])                                          # parameter sharding: + the units' all-gathers (forward and backward)
     assert f["comm"]["collectives_per_step"] > c["collectives_per_step"] and f["comm"]["comm_bytes_per_step"] > c["comm_bytes_per_step"]
     t = run(["--tensor-par", "2"])
@@ -343,6 +345,9 @@ def test_bench_single_rank_line_with_baselines(tmp_path):
     assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "bf16" and "workload" in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["unit"] == "TFLOP/s"
+    # the step's figure: executed FLOPs per step / step time (one "launch" = one step), the GEMM family beside it
+    assert abs(rf["achieved"] * 1e12 - rf["algorithmic_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3)) < 1e-6 * rf["achieved"] * 1e12
+    assert abs(rf["frac"] - d["step_model"]["mfma_frac_of_peak_executed"]) < 1e-12 and d["roofline_gemm"]["frac"] >= rf["frac"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     ge = d["gpu_eager_baseline"]

@@ -13,6 +13,8 @@ import pytest
 import torch
 import torch.nn as nn
 
+from tests._child import free_port, run_child
+
 pytestmark = pytest.mark.gpu
 
 CONST = ["land_sea_mask", "orography", "lattitude", "landcover"]
@@ -128,7 +130,11 @@ def test_engine_adamw_trajectory_vs_reference_golden(golden_dir, tag):
     assert torch.equal(w._o2c.float(), w.data.to(torch.bfloat16).float())
 
 
-def test_sharded_optimizer_matches_replicated_engine(golden_dir, monkeypatch):
+def test_sharded_optimizer_matches_replicated_engine(golden_dir):
+    run_child(__file__, "child_sharded_optimizer_matches_replicated_engine", golden_dir)
+
+
+def child_sharded_optimizer_matches_replicated_engine(golden_dir):
     """shard_optimizer=True on a single-rank RCCL group with the collectives forced on (the in-place reduce-scatter and
     all-gather really run).  Fed the same gradient buffers, the sharded engine's scaler + AdamW step leaves parameters,
     bf16 compute copies and (gathered) moments bit-identical to the all-reduce engine's, over three steps; a
@@ -139,9 +145,7 @@ def test_sharded_optimizer_matches_replicated_engine(golden_dir, monkeypatch):
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.models.hub.components.vit_blocks import Block
     from climate_learn.trainer import training_step
-    monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
-    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29655")
+    os.environ.update(ORBIT2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -194,6 +198,10 @@ def test_sharded_optimizer_matches_replicated_engine(golden_dir, monkeypatch):
 
 
 def test_graphed_step_matches_eager_and_draws_new_masks():
+    run_child(__file__, "child_graphed_step_matches_eager_and_draws_new_masks")
+
+
+def child_graphed_step_matches_eager_and_draws_new_masks():
     """zero_grad + forward + loss + backward captured in a hipGraph: the first replay reproduces the eager step that
     uses the same seeds and the same device-side salt (loss and every gradient bucket bit for bit, except the var-agg
     tables' atomically accumulated gradients), later replays draw other dropout masks, and training through the graph
@@ -255,7 +263,11 @@ def test_graphed_step_matches_eager_and_draws_new_masks():
         _hip.seed_salt(0, add=False)
 
 
-def test_graphed_step_captures_the_bucket_allreduces(monkeypatch):
+def test_graphed_step_captures_the_bucket_allreduces():
+    run_child(__file__, "child_graphed_step_captures_the_bucket_allreduces")
+
+
+def child_graphed_step_captures_the_bucket_allreduces():
     """with the collectives forced on (single-rank RCCL group) the bucket all-reduces issued on the communication
     stream during backward are captured into the hipGraph; replays keep producing the eager result"""
     import torch.distributed as dist
@@ -266,9 +278,7 @@ def test_graphed_step_captures_the_bucket_allreduces(monkeypatch):
     from climate_learn.models.hub.components.vit_blocks import Block
     from oracle.harness import build_pair
     from climate_learn.trainer import training_step
-    monkeypatch.setenv("ORBIT2_FORCE_COLLECTIVES", "1")
-    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29657")
+    os.environ.update(ORBIT2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -452,7 +462,8 @@ def test_odd_token_count_grid_trains():
     from oracle.harness import build_pair, nerr
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.trainer import training_step
-    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(D=128, depth=2, heads=2, grid=(10, 20), B=3, seed=11)
+    from oracle.harness import PINNED_CASES
+    model, sd, cfg, O, x, y, in_vars, out_vars = build_pair(**PINNED_CASES["odd_grid"])
     dev = torch.device("cuda:0")
     model = model.to(dev).eval()
     vw = {"total_precipitation_24hr": 1.0}
@@ -462,9 +473,8 @@ def test_odd_token_count_grid_trains():
     ref = O.training_loss(sdo, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw)
     ref.backward()
     assert abs(float(loss) - float(ref)) / abs(float(ref)) < 2e-2
-    from oracle.harness import grad_tolerance, oracle_bf16_spread
-    spread = oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, "bayesian_tv", vw,
-                                fp32_grads={k: v.grad.detach() for k, v in sdo.items() if v.grad is not None})
+    from oracle.harness import grad_tolerance, reference_spread
+    spread = reference_spread("odd_grid", sd, x, y)         # the reference's own bf16 movement on this case (committed fixture)
     for name, p in (("head.0.weight", model.head[0].weight), ("blocks.1.mlp.fc2.weight", model.blocks[1].mlp.fc2.weight),
                     ("blocks.0.attn.qkv.weight", model.blocks[0].attn.qkv.weight),
                     ("blocks.0.attn.proj.bias", model.blocks[0].attn.proj.bias), ("blocks.1.norm1.weight", model.blocks[1].norm1.weight)):
@@ -524,6 +534,10 @@ def test_checkpoint_roundtrip_resumes_identically(tmp_path):
 
 
 def test_loss_scaler_dynamics_growth_overflow_skip_and_floor():
+    run_child(__file__, "child_loss_scaler_dynamics_growth_overflow_skip_and_floor")
+
+
+def child_loss_scaler_dynamics_growth_overflow_skip_and_floor():
     """HipGradScaler (the ShardedGradScaler the reference intends, driver :493-497,732-742): the scale doubles after
     `growth_interval` clean steps; a non-finite gradient makes the fused AdamW skip the update ON DEVICE (parameters,
     moments and step count untouched), halves the scale, and the scale never goes below `min_scale`; a graphed step

@@ -105,27 +105,24 @@ def _worker(rank, world, port, layout, q):
 
 
 def _spawn(world, layout):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, layout, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=900) for _ in procs]
-    for p in procs:
-        p.join(60)
-    for r in res:
-        assert r[1] == "ok", "rank %d:\n%s" % (r[0], r[2])
-    return res
+    from tests._child import spawn_ranks
+    return spawn_ranks(_worker, world, layout, timeout=900)
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (one RCCL rank per GPU)")
+def _need_gpus(n):
+    # asked when the test RUNS, not when the module is imported (collection must not touch the device runtime)
+    have = torch.cuda.device_count()
+    if have < n:
+        pytest.skip("needs %d GPUs (one RCCL rank per GPU), this box shows %d" % (n, have))
+
+
 def test_full_shard_two_gpus_rccl_matches_replicated():
+    _need_gpus(2)
     print(_spawn(2, "full"))
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 4, reason="needs 4 GPUs (2 shards x 2 replicas)")
 def test_hybrid_shard_four_gpus_rccl_matches_replicated():
+    _need_gpus(4)
     print(_spawn(4, "hybrid"))
 
 

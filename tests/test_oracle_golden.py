@@ -230,3 +230,21 @@ def test_eval_metrics_match_reference(golden_dir):
     assert np.allclose(O.acc(pred, target, clim, False, lw).numpy(), z["lat_acc"], rtol=2e-5, atol=2e-6)
     assert np.allclose(float(O.acc(pred, target, clim, True, lw)), z["lat_acc.agg"], rtol=2e-5, atol=2e-6)
     assert np.allclose(O.acc(pred, target, clim).numpy(), z["acc_unit_weights"], rtol=2e-5, atol=2e-6)
+
+
+def test_committed_bf16_spreads_belong_to_the_seeded_cases(golden_dir):
+    """tests/golden/bf16_spread_configs.npz (the reference's bf16-vs-fp32 movement, the GPU tolerance's yardstick at the smoke /
+    interm_117m / odd-grid cases) was written for exactly the cases oracle/harness.py rebuilds from PINNED_CASES; the generator
+    also ran the reference in fp32 against the oracle on those cases and stored the agreement"""
+    from oracle import harness as H
+    z = np.load(os.path.join(golden_dir, "bf16_spread_configs.npz"))
+    for name in ("smoke", "odd_grid"):                       # (interm_117m's weights take ~10 s to draw: covered by the GPU test)
+        sd, cfg, O, x, y, in_vars, out_vars = H.oracle_case(**H.PINNED_CASES[name])
+        sp = H.reference_spread(name, sd, x, y)              # asserts the fingerprint
+        grads = {k for k in sp if not k.startswith("l2.") and k not in ("pred", "loss")}
+        assert grads == set(sd), (name, grads ^ set(sd))
+        assert all(0.0 <= sp[k] < 0.2 for k in grads) and sp["pred"] < 1e-2
+    for name in H.PINNED_CASES:
+        e_pred, e_loss, e_grad = z[name + "/oracle_vs_reference_fp32"]
+        assert e_pred < 1e-4 and e_loss < 1e-5 and e_grad < 2e-3, (name, e_pred, e_loss, e_grad)
+    assert H.grad_tolerance(0.0) == 2e-2 and H.grad_tolerance(0.05) == pytest.approx(0.075) and H.grad_tolerance(0.5) == 0.15

@@ -2,9 +2,13 @@
 against the CPU oracle (oracle/orbit2_oracle.py: lpips_vgg / perceptual), same seeded stand-in weights on both sides.
 bf16 feature maps (the reference runs LPIPS under bf16 FSDP mixed precision) against the fp32 oracle: tolerances are
 bf16-grade and stated per assertion."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
+
+from tests._child import run_child
 
 pytestmark = pytest.mark.gpu
 
@@ -151,7 +155,11 @@ def test_perceptual_metric_object_and_loader(hip, monkeypatch):
         loss(torch.zeros(1, 2, 32, 32).cuda(), torch.zeros(1, 2, 32, 32).cuda())
 
 
-def test_perceptual_lat_mse_matches_oracle_and_graph_capture(hip, monkeypatch):
+def test_perceptual_lat_mse_matches_oracle_and_graph_capture(hip):
+    run_child(__file__, "child_perceptual_lat_mse_matches_oracle_and_graph_capture")
+
+
+def child_perceptual_lat_mse_matches_oracle_and_graph_capture():
     """BASELINE configs[4] "hybrid perceptual + lat-weighted MSE"  = reference `perceptual` (metrics.py:119-187)
     + intended `lat_mse` (metrics.py:295-316): registered as `perceptual_lat_mse`; value and gradient against the oracle's sum
     (same seeded stand-in LPIPS weights on both sides).  The backward keeps the upstream scalar on the device, so the loss can be
@@ -160,8 +168,8 @@ def test_perceptual_lat_mse_matches_oracle_and_graph_capture(hip, monkeypatch):
     import climate_learn as cl
     from climate_learn.metrics.utils import MetricsMetaInfo
     from climate_learn.metrics.lpips_hip import LPIPSVGG16
-    monkeypatch.delenv("ORBIT2_LPIPS_WEIGHTS", raising=False)
-    monkeypatch.setenv("ORBIT2_LPIPS_SYNTHETIC", "1")
+    os.environ.pop("ORBIT2_LPIPS_WEIGHTS", None)
+    os.environ["ORBIT2_LPIPS_SYNTHETIC"] = "1"
     B, H, W = 2, 32, 64
     names = ["total_precipitation_24hr", "2m_temperature_min", "2m_temperature_max"]
     vw = {"total_precipitation_24hr": 1.0, "2m_temperature_min": 10.0, "2m_temperature_max": 10.0}
@@ -192,7 +200,7 @@ def test_perceptual_lat_mse_matches_oracle_and_graph_capture(hip, monkeypatch):
     torch.cuda.current_stream().wait_stream(side)
     sp.grad = None
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
+    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
         lv = loss(sp, st, var_names=names, var_weights=vw)
         (lv * scale).backward()
     scale.fill_(4.0)                                      # the replay reads the CURRENT scalar, on the device

@@ -123,18 +123,8 @@ def _parity_worker(rank, world, port, tag, q):
 
 
 def _spawn(fn, *args, world=2):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=fn, args=(r, world, port) + args + (q,)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(60)
-    for r in res:
-        assert r[1] == "ok", "rank %d:\n%s" % (r[0], r[2])
-    return res
+    from tests._child import spawn_ranks
+    return spawn_ranks(fn, world, *args, timeout=600)
 
 
 @pytest.mark.parametrize("tag", ["v5c1_hd64", "v7c3_hd64"])

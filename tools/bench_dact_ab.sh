@@ -14,5 +14,5 @@ runpy.run_path('bench.py', run_name='__main__')
 python -c "
 import json
 d = json.loads(open('gpurun_out/dact_ab_$d.json').read().strip().splitlines()[-1])
-print('_DACT=$d  %.3f samples/s  %.1f ms/step  gemm roofline %.4f  loss %.5f' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['step_model']['final_loss']), flush=True)"
+print('_DACT=$d  %.3f samples/s  %.1f ms/step  gemm roofline %.4f  loss %.5f' % (d['value'], d['ms_per_step'], d['roofline_gemm']['frac'], d['step_model']['final_loss']), flush=True)"
 done; done

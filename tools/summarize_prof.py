@@ -1,6 +1,7 @@
 """Condenses rocprofv3 CSV output (kernel stats / PMC counter collection) into small text summaries for profiles/."""
 import collections
 import csv
+import os
 import sys
 
 
@@ -61,6 +62,16 @@ def traffic(fetch_csv, write_csv, out):
                 if any(k.startswith(n) for n in names) and r["Counter_Name"] in acc[f]:
                     acc[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
+    # the whole step: every dispatch of the pass (bench.py --steps 1 --warmup 1 = 2 identical steps, nothing else on the device)
+    nsteps = int(os.environ.get("ORBIT2_PMC_STEPS", "2"))
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    for path in (fetch_csv, write_csv):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] in tot:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"])
+    res["step"] = {"steps_in_pass": nsteps, "fetch_bytes_per_step": tot["FETCH_SIZE"] * 2 * 1024 / nsteps,
+                   "write_bytes_per_step": tot["WRITE_SIZE"] * 1024 / nsteps,
+                   "hbm_bytes_per_step": (tot["FETCH_SIZE"] * 2 + tot["WRITE_SIZE"]) * 1024 / nsteps}
     for f, d in acc.items():
         if not d["FETCH_SIZE"]:
             continue
