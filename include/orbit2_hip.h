@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORBIT2_ABI_VERSION 5
+#define ORBIT2_ABI_VERSION 6
 int orbit2_abi_version(void);
 
 /* ---- bf16 MFMA GEMM with fused epilogue ------------------------------------------------
@@ -189,6 +189,17 @@ int orbit2_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream
 int orbit2_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* y = a + b (bf16), used for pos_embed + spatial_embed table (res_slimvit.py:273-281) */
 int orbit2_add_rowvec(const void* a, const void* vec, void* y, int rows, int N, void* stream);
+
+/* ---- position-embedding table of a step (ABI 6) ------------------------------------------------ */
+/* out[nh*nw][D] = bicubic(pe seen as [oh][ow][D]) + sw[:] * res + sb[:]  (fp32; sw, sb both NULL: plain re-grid).
+ * Replaces components/pos_embed.py:103-138 interpolate_pos_embed_on_the_fly (F.interpolate mode="bicubic",
+ * align_corners=False on the [1, L0, D] table, taken only when oh != nh -- otherwise the table is used as it is) and the
+ * Linear(1, D) resolution embedding res_slimvit.py:62,277-281.  D % 4 == 0, sides <= 2048. */
+int orbit2_posembed_fwd(const float* pe, const float* sw, const float* sb, float res, float* out, int oh, int ow, int nh,
+                        int nw, int D, void* stream);
+/* transpose of the re-grid (autograd of the call above w.r.t. pe): dpe[oh*ow][D] from dout[nh*nw][D]; fixed summation
+ * order, no atomics.  (d sb = column sums of dout, d sw = res * d sb: orbit2_colsum.) */
+int orbit2_posembed_bwd(const float* dout, float* dpe, int oh, int ow, int nh, int nw, int D, void* stream);
 
 /* ---- hi-res tail -------------------------------------------------------------------------- */
 /* unpatchify (res_slimvit.py:167-179): t bf16 [B, L, C*(s*p)^2] -> img [B, C, h*s, w*s] (fp32) */

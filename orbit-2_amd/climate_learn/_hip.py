@@ -58,7 +58,7 @@ def lib():
                 "liborbit2_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        if _lib.orbit2_abi_version() != 5:
+        if _lib.orbit2_abi_version() != 6:
             raise HipBackendError("liborbit2_hip.so ABI version mismatch")
     return _lib
 
@@ -409,6 +409,26 @@ def add_rowvec(a, vec, rows, N):
     y = torch.empty_like(a)
     _chk(lib().orbit2_add_rowvec(_p(a), _p(vec), _p(y), rows, N, _stream()), "orbit2_add_rowvec")
     return y
+
+
+def posembed_fwd(pe, sw, sb, res, oh, ow, nh, nw):
+    """[nh*nw, D] fp32 = bicubic re-grid of the [oh*ow, D] table (identity when oh == nh) + sw * res + sb"""
+    _dev(pe, F32, "pos_embed")
+    D = pe.shape[-1]
+    if sw is not None:
+        _dev(sw, F32, "spatial_embed.weight"); _dev(sb, F32, "spatial_embed.bias")
+    out = torch.empty(nh * nw, D, dtype=F32, device=pe.device)
+    _chk(lib().orbit2_posembed_fwd(_p(pe), _p(sw), _p(sb), C.c_float(res), _p(out), oh, ow, nh, nw, D, _stream()),
+         "orbit2_posembed_fwd")
+    return out
+
+
+def posembed_bwd(dout, oh, ow, nh, nw):
+    _dev(dout, F32, "dposres")
+    D = dout.shape[-1]
+    dpe = torch.empty(oh * ow, D, dtype=F32, device=dout.device)
+    _chk(lib().orbit2_posembed_bwd(_p(dout), _p(dpe), oh, ow, nh, nw, D, _stream()), "orbit2_posembed_bwd")
+    return dpe
 
 
 def unpatchify_fwd(t, B, Cc, h, w, p, s):

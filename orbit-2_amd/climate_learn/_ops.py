@@ -634,6 +634,33 @@ def sgemm(A, B, ta=False, tb=False):
 # embedding front-end: folded patch-embed + variable aggregation + proj + pos/res embedding + dropout
 #   (res_slimvit.py:250-284, attention.py:132-183, patch_embed.py:44-52)
 # ------------------------------------------------------------------------------------------------------
+class PosResFn(torch.autograd.Function):
+    """the [L, D] fp32 table a step adds to its tokens: pos_embed re-gridded to the run's token grid (bicubic, only when the
+    heights differ -- components/pos_embed.py:103-138) + the resolution embedding Linear(1, D)(res) (res_slimvit.py:277-281);
+    one HIP launch forward, the re-grid's transpose + two column sums backward"""
+    @staticmethod
+    def forward(ctx, pos_embed, sw, sb, res, oh, ow, nh, nw):
+        pe = pos_embed.reshape(oh * ow, pos_embed.shape[-1])
+        ctx.meta = (float(res), oh, ow, nh, nw, pos_embed.shape)
+        return _hip.posembed_fwd(pe.contiguous(), sw.reshape(-1).contiguous(), sb.contiguous(), float(res), oh, ow, nh, nw)
+
+    @staticmethod
+    def backward(ctx, dout):
+        res, oh, ow, nh, nw, shape = ctx.meta
+        dout = dout.contiguous()
+        if dout.dtype != F32:
+            dout = dout.float()
+        dpe = dsw = dsb = None
+        if ctx.needs_input_grad[0]:
+            dpe = _hip.posembed_bwd(dout, oh, ow, nh, nw).view(shape)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            L, D = dout.shape
+            dsb = torch.empty(D, dtype=F32, device=dout.device)
+            _hip.colsum(dout, L, D, D, dsb)
+            dsw = (dsb * res).view(D, 1)
+        return dpe, dsw, dsb, None, None, None, None, None
+
+
 class EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xgrid, stab, gtab, posres, wp, bp, H, p_drop, grp=None):

@@ -33,12 +33,19 @@ def _orig_grid(num_patches):
 
 def interpolate_pos_embed_on_the_fly(pos_embed, patch_size, new_size=(64, 128)):
     """Bicubic (align_corners=False) resample of the [1, L0, D] table when the token-grid height differs
-    (reference pos_embed.py:103-138)."""
+    (reference pos_embed.py:103-138).  A table on the device goes through the HIP kernel pair
+    (`_ops.PosResFn`, csrc/image.hip orbit2_posembed_fwd / _bwd: the model's per-step path); a HOST table
+    (checkpoint surgery before the model exists on a device) is resampled with torch on the CPU."""
     d = pos_embed.shape[-1]
     oh, ow = _orig_grid(pos_embed.shape[-2])
     nh, nw = new_size[0] // patch_size, new_size[1] // patch_size
     if oh == nh:
         return pos_embed
+    if pos_embed.is_cuda:
+        from .... import _ops  # noqa: E402  (late: the components package is imported while climate_learn is being built)
+        zero = torch.zeros(d, dtype=torch.float32, device=pos_embed.device)
+        out = _ops.PosResFn.apply(pos_embed.float(), zero.view(d, 1), zero, 0.0, oh, ow, nh, nw)
+        return out.view(1, nh * nw, d).to(pos_embed.dtype)
     grid = pos_embed.reshape(-1, oh, ow, d).permute(0, 3, 1, 2)
     grid = F.interpolate(grid, size=(nh, nw), mode="bicubic", align_corners=False)
     return grid.permute(0, 2, 3, 1).flatten(1, 2)

@@ -26,7 +26,7 @@ from ...utils.fused_attn import FusedAttn
 from .components.attention import VariableMapping_Attention
 from .components.mlp import HipLinear
 from .components.patch_embed import PatchEmbed, _ConvParams
-from .components.pos_embed import get_2d_sincos_pos_embed, interpolate_pos_embed_on_the_fly
+from .components.pos_embed import _orig_grid, get_2d_sincos_pos_embed
 from .components.vit_blocks import Block, HipLayerNorm
 from .utils import register
 
@@ -175,9 +175,14 @@ class Res_Slim_ViT(nn.Module):
         return stab, gtab
 
     def _posres(self):
-        pe = interpolate_pos_embed_on_the_fly(self.pos_embed, self.patch_size, self.img_size)[0]        # [L, D]
-        res = float(self.spatial_resolution)
-        return pe + (self.spatial_embed.weight[:, 0] * res + self.spatial_embed.bias).view(1, -1)
+        """[L, D] fp32: pos_embed on the run's token grid (bicubic re-grid when the grid differs from the one the table
+        was built on, reference pos_embed.py:103-138) + spatial_embed(resolution) (reference :277-281) -- one HIP launch"""
+        oh, ow = _orig_grid(self.pos_embed.shape[-2])
+        nh, nw = self.img_size[0] // self.patch_size, self.img_size[1] // self.patch_size
+        if oh == nh:
+            ow = nw                                      # (the reference uses the table as it is whenever the heights agree)
+        return _ops.PosResFn.apply(self.pos_embed, self.spatial_embed.weight, self.spatial_embed.bias,
+                                   float(self.spatial_resolution), oh, ow, nh, nw)
 
     # ------------------------------------------------------------------ forward (res_slimvit.py:245-338)
     def forward_encoder(self, x, variables):

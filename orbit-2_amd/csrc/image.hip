@@ -501,3 +501,146 @@ extern "C" int orbit2_eval_moments(const float* pred, const float* target, int H
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
+
+// ---- position-embedding table of a step: bicubic re-grid + resolution embedding --------------------------------------------
+// out[(oy nw + ox)][:] = bicubic(pe)[oy][ox][:] + sw[:] * res + sb[:]
+// (components/pos_embed.py:103-138 interpolate_pos_embed_on_the_fly: the [1, L0, D] table seen as a channel-last [oh][ow][D] grid,
+// F.interpolate(mode="bicubic", align_corners=False) to [nh][nw], only when the heights differ; res_slimvit.py:277-281: + the
+// Linear(1, D) spatial embedding of the scalar resolution.)  fp32 throughout, the table is a parameter.
+// Bicubic as ATen defines it: source coordinate s = (in / out) (o + 0.5) - 0.5 (not clamped), base = floor(s), t = s - base, taps
+// base - 1 .. base + 2 with indices clamped to the grid, cubic-convolution weights with A = -0.75; a pixel = the four row
+// interpolants (left to right) combined top to bottom.  Channel-last, so a pixel's D values are contiguous: one workgroup per
+// pixel, lanes over D in float4.
+namespace {
+constexpr int PE_MAX_SIDE = 2048;
+
+__device__ __forceinline__ void cubic_taps(int o, int n_in, int n_out, int idx[4], float w[4]) {
+  const float scale = (float)n_in / (float)n_out;
+  const float s = scale * ((float)o + 0.5f) - 0.5f;
+  const float fl = floorf(s);
+  const float t = s - fl;
+  const int base = (int)fl;
+  constexpr float A = -0.75f;
+  const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = base - 1 + k;
+    idx[k] = i < 0 ? 0 : (i > n_in - 1 ? n_in - 1 : i);
+  }
+}
+
+template <bool SAME>
+__global__ __launch_bounds__(256) void posembed_fwd_kernel(const float* __restrict__ pe, const float* __restrict__ sw,
+                                                           const float* __restrict__ sb, float res, float* __restrict__ out,
+                                                           int oh, int ow, int nh, int nw, int D) {
+  const int pix = blockIdx.x, oy = pix / nw, ox = pix - oy * nw;
+  int iy[4], ix[4];
+  float wy[4], wx[4];
+  if (!SAME) {
+    cubic_taps(oy, oh, nh, iy, wy);
+    cubic_taps(ox, ow, nw, ix, wx);
+  }
+  float* o = out + (size_t)pix * D;
+  for (int d = threadIdx.x * 4; d < D; d += 256 * 4) {
+    float4 acc;
+    if (SAME) {
+      acc = *reinterpret_cast<const float4*>(pe + (size_t)pix * D + d);
+    } else {
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float* row = pe + ((size_t)iy[a] * ow) * D + d;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float4 v = *reinterpret_cast<const float4*>(row + (size_t)ix[b] * D);
+          r.x += v.x * wx[b]; r.y += v.y * wx[b]; r.z += v.z * wx[b]; r.w += v.w * wx[b];
+        }
+        acc.x += r.x * wy[a]; acc.y += r.y * wy[a]; acc.z += r.z * wy[a]; acc.w += r.w * wy[a];
+      }
+    }
+    if (sw) {
+      const float4 w4 = *reinterpret_cast<const float4*>(sw + d), b4 = *reinterpret_cast<const float4*>(sb + d);
+      acc.x += w4.x * res + b4.x; acc.y += w4.y * res + b4.y; acc.z += w4.z * res + b4.z; acc.w += w4.w * res + b4.w;
+    }
+    *reinterpret_cast<float4*>(o + d) = acc;
+  }
+}
+
+// transpose of the re-grid: dpe[iy][ix][:] = sum_{oy, ox} Wy[oy][iy] Wx[ox][ix] dout[oy][ox][:].  One workgroup per SOURCE pixel:
+// it first tabulates, in LDS, the weight every output row / column gives this source row / column (dense over nh / nw, mostly
+// zero: a source row feeds ~4 in/out ... 4 out/in output rows, more at a clamped border), then walks the non-zero pairs in
+// ascending (oy, ox) order -- a fixed summation order, no atomics (the same bits on every run and every rank).
+__global__ __launch_bounds__(256) void posembed_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dpe, int oh, int ow,
+                                                           int nh, int nw, int D) {
+  __shared__ float wyd[PE_MAX_SIDE], wxd[PE_MAX_SIDE];
+  const int pix = blockIdx.x, sy = pix / ow, sx = pix - sy * ow;
+  for (int o = threadIdx.x; o < nh; o += 256) {
+    int idx[4];
+    float w[4], s = 0.f;
+    cubic_taps(o, oh, nh, idx, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (idx[k] == sy) ? w[k] : 0.f;
+    wyd[o] = s;
+  }
+  for (int o = threadIdx.x; o < nw; o += 256) {
+    int idx[4];
+    float w[4], s = 0.f;
+    cubic_taps(o, ow, nw, idx, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (idx[k] == sx) ? w[k] : 0.f;
+    wxd[o] = s;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x * 4; d < D; d += 256 * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = 0; oy < nh; ++oy) {
+      const float wy = wyd[oy];
+      if (wy == 0.f) continue;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ox = 0; ox < nw; ++ox) {
+        const float wx = wxd[ox];
+        if (wx == 0.f) continue;
+        const float4 v = *reinterpret_cast<const float4*>(dout + ((size_t)oy * nw + ox) * D + d);
+        r.x += v.x * wx; r.y += v.y * wx; r.z += v.z * wx; r.w += v.w * wx;
+      }
+      acc.x += r.x * wy; acc.y += r.y * wy; acc.z += r.z * wy; acc.w += r.w * wy;
+    }
+    *reinterpret_cast<float4*>(dpe + (size_t)pix * D + d) = acc;
+  }
+}
+}  // namespace
+
+extern "C" int orbit2_posembed_fwd(const float* pe, const float* sw, const float* sb, float res, float* out, int oh, int ow,
+                                   int nh, int nw, int D, void* stream) {
+  if (!pe || !out || (sw == nullptr) != (sb == nullptr) || oh <= 0 || ow <= 0 || nh <= 0 || nw <= 0 || D <= 0 || (D & 3))
+    return O2_ERR_ARG;
+  if (nh > PE_MAX_SIDE || nw > PE_MAX_SIDE || oh > PE_MAX_SIDE || ow > PE_MAX_SIDE) return O2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (oh == nh) {                 // the reference re-grids only when the heights differ (pos_embed.py:117)
+    if (ow != nw) return O2_ERR_ARG;
+    hipLaunchKernelGGL((posembed_fwd_kernel<true>), dim3(nh * nw), dim3(256), 0, s, pe, sw, sb, res, out, oh, ow, nh, nw, D);
+  } else {
+    hipLaunchKernelGGL((posembed_fwd_kernel<false>), dim3(nh * nw), dim3(256), 0, s, pe, sw, sb, res, out, oh, ow, nh, nw, D);
+  }
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_posembed_bwd(const float* dout, float* dpe, int oh, int ow, int nh, int nw, int D, void* stream) {
+  if (!dout || !dpe || oh <= 0 || ow <= 0 || nh <= 0 || nw <= 0 || D <= 0 || (D & 3)) return O2_ERR_ARG;
+  if (nh > PE_MAX_SIDE || nw > PE_MAX_SIDE || oh > PE_MAX_SIDE || ow > PE_MAX_SIDE) return O2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (oh == nh) {
+    if (ow != nw) return O2_ERR_ARG;
+    if (hipMemcpyAsync(dpe, dout, sizeof(float) * (size_t)nh * nw * D, hipMemcpyDeviceToDevice, s) != hipSuccess) return O2_ERR_LAUNCH;
+    return O2_OK;
+  }
+  hipLaunchKernelGGL(posembed_bwd_kernel, dim3(oh * ow), dim3(256), 0, s, dout, dpe, oh, ow, nh, nw, D);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

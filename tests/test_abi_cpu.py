@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export " + n
-    assert lib.orbit2_abi_version() == 5
+    assert lib.orbit2_abi_version() == 6
 
 
 def test_gemm_args_struct_matches_header():

@@ -1,6 +1,7 @@
 """GPU parity tests: every C-ABI entry point against the CPU oracle (oracle/orbit2_oracle.py, plain
 PyTorch fp32) on the same seeded inputs.  bf16 kernels are compared against the fp32 oracle evaluated on
 the bf16-rounded inputs; tolerance = normalised max error (max|a-b| / max|b|), stated per test."""
+import os
 import math
 
 import numpy as np
@@ -957,3 +958,56 @@ def test_backward_gemm_forms_own_kernel(hip, monkeypatch):
         ref = torch.einsum("mk,nk->mn", Af if a_kc else Af.t(), Bf if b_kc else Bf.t()) + beta * C0.float().cpu()
         assert nerr(o.cpu(), ref) < 1e-2, (a_kc, b_kc, beta)
     assert not hasattr(hip, "plain_gemm") and not hasattr(hip, "PLAIN_GEMM_LIBRARY")
+
+
+# ---- position-embedding table: bicubic re-grid + resolution embedding -----------------------------------------------
+def test_posembed_regrid_matches_reference_golden(hip, golden_dir):
+    """orbit2_posembed_fwd against what the REFERENCE's interpolate_pos_embed_on_the_fly returned for the same table
+    (tests/golden/components_tiny.npz pos.*, written by make_golden.py from components/pos_embed.py:103-138): up-sampling,
+    down-sampling and the same-grid pass-through"""
+    from climate_learn.models.hub.components.pos_embed import interpolate_pos_embed_on_the_fly
+    z = np.load(os.path.join(golden_dir, "components_tiny.npz"))
+    pe = torch.from_numpy(z["pos.in"]).cuda()
+    for key, size in (("pos.up_12x24", (24, 48)), ("pos.down_2x4", (4, 8)), ("pos.same", (8, 16))):
+        got = interpolate_pos_embed_on_the_fly(pe, 2, size)
+        ref = torch.from_numpy(z[key])
+        assert got.shape == ref.shape and got.is_cuda
+        assert float((got.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6, key
+
+
+@pytest.mark.parametrize("oh,nh,D", [(8, 16, 128), (16, 8, 64), (16, 64, 1024), (12, 45, 256), (64, 16, 512), (16, 16, 256)])
+def test_posembed_table_forward_backward(hip, oh, nh, D):
+    """the whole table a step adds to its tokens, out = bicubic(pos_embed) + w * res + b, and its three gradients against torch on
+    the CPU (the oracle's pos_embed_for_grid is F.interpolate): fp32, <= 1e-5 of the largest value; the backward is a
+    fixed-order gather (two runs agree bit for bit)"""
+    from climate_learn import _ops
+    import torch.nn.functional as F
+    ow, nw = 2 * oh, 2 * nh
+    g = torch.Generator().manual_seed(oh * 131 + nh)
+    pe = torch.randn(1, oh * ow, D, generator=g)
+    sw, sb, res = torch.randn(D, 1, generator=g), torch.randn(D, generator=g), 0.703
+    go = torch.randn(nh * nw, D, generator=g)
+    pr, wr, br = pe.clone().requires_grad_(), sw.clone().requires_grad_(), sb.clone().requires_grad_()
+    grid = pr.reshape(1, oh, ow, D).permute(0, 3, 1, 2)
+    if oh != nh:
+        grid = F.interpolate(grid, size=(nh, nw), mode="bicubic", align_corners=False)
+    ref = grid.permute(0, 2, 3, 1).reshape(nh * nw, D) + (wr[:, 0] * res + br).view(1, -1)
+    ref.backward(go)
+    pg, wg, bg = pe.cuda().requires_grad_(), sw.cuda().requires_grad_(), sb.cuda().requires_grad_()
+    out = _ops.PosResFn.apply(pg, wg, bg, res, oh, ow, nh, nw)
+    out.backward(go.cuda())
+    err = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max() / b.detach().abs().max())
+    assert out.shape == (nh * nw, D) and err(out, ref) < 1e-5
+    assert err(pg.grad, pr.grad) < 1e-5 and err(wg.grad, wr.grad) < 1e-5 and err(bg.grad, br.grad) < 1e-5
+    first = pg.grad.clone()
+    pg.grad = None
+    _ops.PosResFn.apply(pg, wg, bg, res, oh, ow, nh, nw).backward(go.cuda())
+    assert torch.equal(first, pg.grad)
+
+
+def test_posembed_argument_checks(hip):
+    x = torch.zeros(8 * 16, 6, device="cuda")
+    assert hip.lib().orbit2_posembed_fwd(hip._p(x), None, None, hip.C.c_float(0.0), hip._p(x), 8, 16, 8, 16, 6, None) == -1   # D % 4
+    y = torch.zeros(8 * 16, 8, device="cuda")
+    assert hip.lib().orbit2_posembed_fwd(hip._p(y), hip._p(y), None, hip.C.c_float(0.0), hip._p(y), 8, 16, 8, 16, 8, None) == -1  # sw without sb
+    assert hip.lib().orbit2_posembed_bwd(hip._p(y), hip._p(y), 8, 16, 8, 12, 8, None) == -1       # same height, other width
