@@ -159,6 +159,10 @@ int orbit2_varagg_fwd(const float* x, const float* stab, const float* gtab, void
 int64_t orbit2_varagg_bwd_ws_floats(int B, int V, int h, int w, int H, int D);
 int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
                       float* dgtab, int B, int V, int h, int w, int H, int D, float* ws, void* stream);
+/* 1 if orbit2_varagg_bwd sums the table gradients in a fixed order for this shape (bitwise reproducible), 0 if it takes the
+ * scalar fallback that accumulates them with fp32 atomics (head dim not 64 / 128 / 256, 5 V > 128, ORBIT2_VARAGG_SCALAR set):
+ * callers that keep replicas of the tables in lock-step without exchanging gradients need to know (dist/tp.py ReplicaGuard) */
+int orbit2_varagg_bwd_is_fixed_order(int B, int V, int h, int w, int H, int D);
 
 /* ---- elementwise / reductions ------------------------------------------------------------- */
 /* dym = dy * dropmask * rowscale (backward of the dropout/DropPath epilogue); dym may alias dy */

@@ -329,9 +329,17 @@ def _ws(query, args, device):
     return torch.empty(n, dtype=F32, device=device)
 
 
+# set once a gradient was accumulated with atomics (summation order not fixed): dist/tp.py ReplicaGuard then exchanges the
+# tensor-parallel replicas' gradients instead of relying on their bitwise agreement
+atomics_in_grad_path = False
+
+
 def varagg_bwd(x, gtab, attw, dz, H, D):
+    global atomics_in_grad_path
     _dev(x, F32, "x"); _dev(gtab, F32, "gtab"); _dev(attw, F32, "attw"); _dev(dz, BF, "dz")
     B, V, h, w = x.shape
+    if not atomics_in_grad_path and not lib().orbit2_varagg_bwd_is_fixed_order(B, V, h, w, H, D):
+        atomics_in_grad_path = True
     dstab = torch.zeros(H, V, 5, dtype=F32, device=x.device)
     dgtab = torch.zeros(V, 5, D, dtype=F32, device=x.device)
     ws = _ws(lib().orbit2_varagg_bwd_ws_floats, (B, V, h, w, H, D), x.device)

@@ -109,11 +109,11 @@ class HipDataParallel(nn.Module):
                  is_lowp=None, sync_module_states: bool = True, overlap: bool = True,
                  shard_optimizer: bool = False, replica_group=None):
         """replica_group: the tensor-parallel group of this rank (dist/tp.py).  The parameters that are NOT split over it are
-        replicas.  Every kernel on their gradient path is bitwise reproducible (round 4: the conv weight / variable-aggregation
-        table gradients, once fp32 atomics, are two-stage fixed-order sums) and the ranks of a group see identical activations,
-        so the replicas' gradients agree bit for bit without any exchange -- the per-step broadcast from the group's first
-        rank that rounds 2-3 needed is gone; `replica_grad_views()` exposes the ranges (laid out first inside every unit) so
-        that tests can compare them across the group."""
+        replicas; their gradient ranges are laid out first inside every unit (`replica_grad_views()`).  Where every kernel on
+        their gradient path sums in a fixed order AND the group is the whole job, the replicas' gradients agree bit for bit and
+        nothing is exchanged (a periodic exact checksum across the group verifies it); with data parallelism beside the group
+        (each column reduces over its own communicator) or an atomics-accumulating kernel on the path, the ranges are broadcast
+        from the group's first rank after the reduction: dist/tp.py ReplicaGuard."""
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -121,6 +121,8 @@ class HipDataParallel(nn.Module):
                                                and dist.get_world_size(replica_group) > 1) else None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.replica_guard = _tp.ReplicaGuard(self.replica_group, self.world) if self.replica_group is not None else None
+        self._replicas_synced = False
         self.shard = bool(shard_optimizer)
         # ORBIT2_FORCE_COLLECTIVES=1 issues the bucket all-reduces even on a single rank (exercises the RCCL path
         # -- streams, async handles, bf16 reduction -- on a 1-GPU box)
@@ -272,6 +274,7 @@ class HipDataParallel(nn.Module):
                 if hasattr(p, "_o2g"):
                     p._o2_fresh = True
         self._launched = []
+        self._replicas_synced = False
 
     def _hi_hook(self, p):
         self.grad_ready(p)
@@ -372,6 +375,9 @@ class HipDataParallel(nn.Module):
                 cs.stalls.append((e0, e1))
             else:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.replica_guard is not None and not self._replicas_synced:
+            self.replica_guard.after_reduction(self.replica_grad_views())
+            self._replicas_synced = True
 
     def replica_grad_views(self):
         """gradient ranges of the parameters replicated over the tensor-parallel group (tests: equal on every rank of it)"""

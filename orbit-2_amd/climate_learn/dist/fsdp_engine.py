@@ -74,8 +74,8 @@ class HipFullyShardedDataParallel(nn.Module):
         14-24).  The model then holds the rank's head / column slices; the shard and replicate groups are the data-parallel
         ranks of ONE tensor-parallel column, so chunks are cut from the rank's own slices and the tensor-parallel collectives of
         the model are untouched.  Parameters that are NOT split over tp_group (LayerNorms, embeddings, convolutions) are
-        replicas: laid out first inside every unit; their gradients agree bit for bit across the group without any exchange
-        (every kernel on their path is bitwise reproducible since round 4, see HipDataParallel)."""
+        replicas: laid out first inside every unit; whether their reduced gradient ranges are exchanged over the group or only
+        verified is decided by dist/tp.py ReplicaGuard (see HipDataParallel)."""
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -87,6 +87,9 @@ class HipFullyShardedDataParallel(nn.Module):
         self.replicas = dist.get_world_size(self.rg) if self.rg is not None else 1
         self.grad_world = self.world * self.replicas
         self.found_inf_groups = [self.pg] + ([self.rg] if self.rg is not None else [])
+        from . import tp as _tp
+        self.replica_guard = _tp.ReplicaGuard(self.tp_group, self.grad_world) if self.tp_group is not None else None
+        self._replicas_synced = False
         self.shard = True
         self.shard_params = True
         import os as _os
@@ -422,6 +425,7 @@ class HipFullyShardedDataParallel(nn.Module):
                 if hasattr(p, "_o2_fresh"):
                     p._o2_fresh = True
         self._launched = []
+        self._replicas_synced = False
 
     def _hi_hook(self, p):
         self.grad_ready(p)
@@ -525,6 +529,13 @@ class HipFullyShardedDataParallel(nn.Module):
                 cs.stalls.append((e0, e1))
             else:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.replica_guard is not None and not self._replicas_synced:
+            self.replica_guard.after_reduction(self.replica_grad_views())
+            self._replicas_synced = True
+
+    def replica_grad_views(self):
+        """reduced gradient ranges (this rank's chunks) of the parameters replicated over the tensor-parallel group"""
+        return [v for u in self.units for v in u.rep_views]
 
     def gather_params(self):
         """after the local AdamW: the resident (root) unit's compute copies are re-assembled from the ranks' chunks; sharded

@@ -89,6 +89,63 @@ def broadcast_first(t: torch.Tensor, group) -> torch.Tensor:
     return t
 
 
+class ReplicaGuard:
+    """Keeps the parameters that are REPLICATED over a tensor-parallel group identical on its ranks.
+
+    Their gradients agree bit for bit without any exchange as long as (a) every kernel on their gradient path sums in a fixed
+    order and (b) all ranks of the group see the same reduced gradient.  (a) holds for the MFMA variable-aggregation backward,
+    not for its scalar fallback (fp32 atomics; head dims other than 64 / 128 / 256, more than 25 variables, or
+    ORBIT2_VARAGG_SCALAR -- `_hip.atomics_in_grad_path` records its use).  (b) holds when the group's ranks are the whole job;
+    with data parallelism beside it each tensor-parallel column reduces its replicas over a DIFFERENT communicator and GPU set,
+    and ring / tree order -- hence the bf16 / fp32 summation order -- need not match between columns.  An ulp of difference in a
+    near-zero gradient becomes +-lr under AdamW and the replicas drift apart silently.  Policy (ORBIT2_TP_REPLICA_SYNC):
+      auto (default)  broadcast the replica gradient ranges from the group's first rank after the data-parallel reduction
+                      whenever (a) or (b) is not guaranteed; otherwise no exchange, but every `check_every`-th step (and the
+                      first) an exact checksum of the ranges is compared across the group and a mismatch raises;
+      broadcast       always broadcast;   check  never broadcast, always compare;   off  neither."""
+
+    def __init__(self, group, data_world: int, check_every: int = 100):
+        import os
+        self.group, self.data_world, self.check_every = group, int(data_world), int(check_every)
+        self.mode = os.environ.get("ORBIT2_TP_REPLICA_SYNC", "auto")
+        if self.mode not in ("auto", "broadcast", "check", "off"):
+            raise ValueError("ORBIT2_TP_REPLICA_SYNC must be auto, broadcast, check or off")
+        self.steps = self.broadcasts = self.checks = 0
+
+    def needs_broadcast(self) -> bool:
+        from .. import _hip
+        if self.mode == "broadcast":
+            return True
+        return self.mode == "auto" and (self.data_world > 1 or _hip.atomics_in_grad_path)
+
+    def after_reduction(self, views) -> None:
+        """once per step, when the data-parallel reduction of `views` (the replica gradient ranges) has completed on the
+        current stream"""
+        if self.group is None or self.mode == "off" or not views:
+            return
+        self.steps += 1
+        if self.needs_broadcast():
+            for v in views:
+                broadcast_first(v, self.group)
+            self.broadcasts += 1
+            return
+        if self.mode == "check" or self.steps == 1 or self.steps % self.check_every == 0:
+            # exact and order-free: the int64 sum of the raw words of every range (any flipped bit changes it), and the
+            # word count; equal on all ranks <=> max == min
+            sums = []
+            for v in views:
+                raw = v.view(torch.int16) if v.element_size() == 2 else v.view(torch.int32)
+                sums.append(raw.sum(dtype=torch.int64))
+            mine = torch.stack(sums)
+            hi, lo = all_reduce_max(mine.clone(), self.group), -all_reduce_max(-mine.clone(), self.group)
+            self.checks += 1
+            if not torch.equal(hi, lo):
+                bad = [i for i in range(len(views)) if int(hi[i]) != int(lo[i])]
+                raise RuntimeError("tensor-parallel replicas disagree: the gradient ranges %s of the parameters replicated over "
+                                   "the group differ between its ranks at step %d (a non-reproducible kernel or reduction "
+                                   "order on their path); run with ORBIT2_TP_REPLICA_SYNC=broadcast" % (bad, self.steps))
+
+
 class IdentityFwdAllReduceBwd(torch.autograd.Function):
     """input of a column-parallel Linear: identity forward, SUM of the partial input gradients backward
     (reference `F_Identity_B_AllReduce`, utils/dist_functions.py:430-445)"""

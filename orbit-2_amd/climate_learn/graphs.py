@@ -54,6 +54,14 @@ class GraphedTrainStep:
         if getattr(engine.module, "tensor_par_size", 1) > 1:
             raise NotImplementedError("GraphedTrainStep covers the data-parallel step; tensor-parallel steps (large "
                                       "models, not launch-bound) run eagerly")
+        if getattr(engine, "shard_params", False):
+            # The parameter-sharding engine is eager-only.  Its step does record into a capture (per-unit all-gathers, pooled
+            # buffers, reduce-scatters, cross-stream hand-over events), but hipStreamEndCapture then segfaults inside the runtime
+            # -- in round 3, and again in round 5 with every pool event of the uncaptured warm-up forgotten before the capture so
+            # that each wait followed a record made inside it.  It exists for models whose parameters do not fit a
+            # GPU replicated; those are not launch-bound, which is all a replayed graph buys.
+            raise NotImplementedError("GraphedTrainStep: the parameter-sharding engine (HipFullyShardedDataParallel) runs eagerly; "
+                                      "use HipDataParallel (optionally shard_optimizer=True) for a captured step")
         self.engine, self.loss_metric, self.var_weights, self.scaler = engine, loss_metric, var_weights, scaler
         self.device = engine.device
         self.x = x.to(self.device).clone()           # static input buffers: refill with .copy_ between replays

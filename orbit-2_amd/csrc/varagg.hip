@@ -474,6 +474,18 @@ extern "C" int64_t orbit2_varagg_bwd_ws_floats(int B, int V, int h, int w, int H
   return (int64_t)varagg_bwd_splits((int)ntok, H, nullptr) * ((int64_t)H * V * 5 + (int64_t)V * 5 * D);
 }
 
+// 1 when orbit2_varagg_bwd takes the two-stage fixed-order path for this shape (bitwise reproducible gradients), 0 when it falls
+// back to the scalar kernel whose table gradients are accumulated with fp32 atomics
+static bool varagg_bwd_fixed_order(int64_t ntok, int V, int H, int D) {
+  static const bool force_scalar = getenv("ORBIT2_VARAGG_SCALAR") != nullptr;   // debugging aid: the fp32 VALU kernel
+  const int dh = D / H;
+  return !force_scalar && (dh == 64 || dh == 128 || dh == 256) && 5 * V <= VM_NV && ntok < (1ll << 31) - 64;
+}
+extern "C" int orbit2_varagg_bwd_is_fixed_order(int B, int V, int h, int w, int H, int D) {
+  if (va_check(B, V, h, w, H, D)) return 0;
+  return varagg_bwd_fixed_order((int64_t)B * (h / 2) * (w / 2), V, H, D) ? 1 : 0;
+}
+
 extern "C" int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
                                  float* dgtab, int B, int V, int h, int w, int H, int D, float* ws, void* stream) {
   if (!x || !gtab || !attw || !dz || !dstab || !dgtab || !ws) return O2_ERR_ARG;
@@ -481,8 +493,7 @@ extern "C" int orbit2_varagg_bwd(const float* x, const float* gtab, const float*
   if (rc) return rc;
   const int64_t ntok = (int64_t)B * (h / 2) * (w / 2);
   const int dh = D / H;
-  static const bool force_scalar = getenv("ORBIT2_VARAGG_SCALAR") != nullptr;   // debugging aid: the fp32 VALU kernel
-  if (!force_scalar && (dh == 64 || dh == 128 || dh == 256) && 5 * V <= VM_NV && ntok < (1ll << 31) - 64) {
+  if (varagg_bwd_fixed_order(ntok, V, H, D)) {
     hipStream_t s = (hipStream_t)stream;
     if (dh == 64) varagg_bwd_mfma_launch<64>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, ws, s);
     else if (dh == 128) varagg_bwd_mfma_launch<128>(x, gtab, attw, dz, dstab, dgtab, B, V, h, w, H, D, (int)ntok, ws, s);

@@ -165,3 +165,19 @@ def child_fully_sharded_engine_matches_replicated_engine(golden_dir):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_graphed_step_refuses_the_parameter_sharding_engine(golden_dir):
+    """the FULL_SHARD engine is eager-only (its capture crashes in hipStreamEndCapture): asking for a captured step
+    is an error at construction, not a crash at capture"""
+    import torch.nn as nn
+    import climate_learn as cl
+    from climate_learn.graphs import GraphedTrainStep
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from tests.test_model_gpu import load, VW
+    c, z, sd, m = load(golden_dir, "v5c1_hd64")
+    eng = cl.HipFullyShardedDataParallel(m.train(), unit_types=(Block, nn.Sequential))
+    batch = (torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), c["in_vars"], c["out_vars"])
+    with pytest.raises(NotImplementedError, match="runs eagerly"):
+        GraphedTrainStep(eng, Bayesian_TV(aggregate_only=True), batch, VW)

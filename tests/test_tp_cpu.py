@@ -111,6 +111,40 @@ def _worker(rank, world, port, q):
         assert torch.equal(x.grad, torch.full((3, 4), 210.0)), x.grad
         t = torch.tensor([float(rank)])
         assert float(tp.all_reduce_max(t, None)) == 1.0
+        # ReplicaGuard: what keeps tensor-parallel replicas identical (advisor r4: do not rely on bitwise agreement where the
+        # reduction order is not pinned)
+        from climate_learn import _hip
+        os.environ.pop("ORBIT2_TP_REPLICA_SYNC", None)
+        same = [torch.arange(40, dtype=torch.float32).to(torch.bfloat16), torch.linspace(-1, 1, 17)]
+        g = tp.ReplicaGuard(tpg, data_world=1, check_every=3)             # the group is the whole job, fixed-order kernels
+        assert not g.needs_broadcast()
+        for _ in range(4):
+            g.after_reduction([v.clone() for v in same])
+        assert g.checks == 2 and g.broadcasts == 0                        # first step and every third
+        bad = [v.clone() for v in same]
+        if rank == 1:
+            bad[1][5] += 1e-7 * (1 + bad[1][5].abs())                     # one ulp-scale difference on one rank
+        g2 = tp.ReplicaGuard(tpg, data_world=1)
+        try:
+            g2.after_reduction(bad)
+            raise AssertionError("a replica mismatch went unnoticed")
+        except RuntimeError as e:
+            assert "replicas disagree" in str(e) and "[1]" in str(e)
+        g3 = tp.ReplicaGuard(tpg, data_world=2)                           # data parallelism beside the group: exchange
+        assert g3.needs_broadcast()
+        g3.after_reduction(bad)
+        assert g3.broadcasts == 1 and torch.equal(bad[1], same[1])       # every rank now holds the first rank's range
+        got = [None, None]
+        dist.all_gather_object(got, bad[1], group=tpg)
+        assert torch.equal(got[0], got[1])
+        _hip.atomics_in_grad_path = True                                  # an atomics-accumulating kernel was used: exchange too
+        assert tp.ReplicaGuard(tpg, data_world=1).needs_broadcast()
+        _hip.atomics_in_grad_path = False
+        os.environ["ORBIT2_TP_REPLICA_SYNC"] = "off"
+        g4 = tp.ReplicaGuard(tpg, data_world=2)
+        g4.after_reduction(bad)
+        assert g4.broadcasts == g4.checks == 0
+        os.environ.pop("ORBIT2_TP_REPLICA_SYNC")
         q.put((rank, "ok"))
     except Exception:
         q.put((rank, traceback.format_exc()))

@@ -173,6 +173,9 @@ def _train_worker(rank, world, port, q):
             assert not scaler.update()
             losses.append(float(loss))
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        # the tensor-parallel group is the whole job and every kernel on the replicas' gradient path sums in a fixed order: the
+        # guard exchanged nothing and its exact cross-rank checksum (first step) found the ranges identical
+        assert eng.replica_guard.broadcasts == 0 and eng.replica_guard.checks >= 1 and eng.replica_guard.steps == 5
         sds = [None] * world
         dist.all_gather_object(sds, ({k: v.cpu() for k, v in eng.state_dict().items()}, losses), group=grp)
         (a, la), (b, lb) = sds
