@@ -56,7 +56,8 @@ typedef struct {
   int ldr, res_mod, res_first;
   int out_fp32;            /* 0: C is bf16, 1: C is fp32 */
   float beta;              /* C = beta*C + result (gradient accumulation) */
-  int tile_hint;           /* 0 = auto; tests / tuning: 128 = 128-tile kernel, 256 = 8-wave 8-phase kernel (K % 64 == 0),
+  int tile_hint;           /* 0 = auto; tests / tuning: 128 = 128-tile kernel on 128 x 128 tiles, 64 = the same kernel on 64-row tiles
+                              (A K-contiguous; auto takes them when the 128 x 128 grid is under two tiles per CU), 256 = 8-wave 8-phase kernel (K % 64 == 0),
                               260 = 4-wave kernel (M, N % 256 == 0, K % 64 == 0), 262 = 4-wave kernel with the runtime epilogue in
                               place of the compile-time kinds */
   int colscale_n;          /* columns n < colscale_n (a multiple of 8; 0 = none) are multiplied by colscale in fp32 right after */

@@ -21,13 +21,14 @@ constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
 // 16 zero bytes every lane may fetch: the source of LDS-DMA pieces that lie past the end of the contraction (K tail)
 __device__ __attribute__((aligned(16))) const unsigned int o2_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <bool KC>
+template <bool KC, int NP = 4>   // NP pieces per wave: 4 = a 128-row tile; 2 = the 64-row tile of a K-contiguous operand
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int r0, int rmax, int k0, int kmax,
                                            char* tile, int wave, int lane) {
+  static_assert(NP == 4 || KC, "the 64-row tile exists for K-contiguous operands only");
   const bool tail = k0 + BK > kmax;   // wave-uniform: only the last k-step of a ragged K pays the per-lane redirect
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = wave * 4 + t;  // LDS-DMA instruction id, 0..15 (1 KiB each)
+  for (int t = 0; t < NP; ++t) {
+    const int i = wave * NP + t;  // LDS-DMA instruction id, 0..15 (1 KiB each)
     const bf16_t* src;
     if (KC) {
       const int row = i * 8 + (lane >> 3);
@@ -329,31 +330,36 @@ __device__ __forceinline__ int xcd_tile_id() {
 
 // one 128x128 output tile (tile `id` of the problem; tiles are walked in groups of 8 tile-rows so neighbours
 // share panels)
-template <bool A_KC, bool B_KC>
+// MT = rows of the tile: 128, or 64 (A K-contiguous only) -- half the rows per workgroup, twice the workgroups: problems whose
+// 128 x 128 tiles number fewer than two per CU (the N = 1024 GEMMs of interm_117m: 256 tiles) then still put TWO workgroups on
+// every CU, and a lone workgroup's exposed waits (fragment reads, the barrier, the LDS-DMA pieces) hide behind its partner's MFMAs
+template <bool A_KC, bool B_KC, int MT = 128>
 __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
                                              int K, int lda, int ldb, int tiles_m, int tiles_n, const Epi& epi,
                                              int id, char* smem) {
+  static_assert(MT == 128 || (MT == 64 && A_KC), "64-row tiles: K-contiguous A");
+  constexpr int FI = MT / 32;            // m-side fragments per wave: 4 (64 rows of 128) or 2 (32 rows of 64)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  constexpr int GROUP = 8;
+  constexpr int GROUP = 8 * (128 / MT);
   const int per_group = GROUP * tiles_n;
   const int grp = id / per_group;
   const int first_m = grp * GROUP;
   const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
   const int tm = first_m + (id % per_group) % gsz;
   const int tn = (id % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * MT, n0 = tn * BN;
 
-  f32x4 acc[4][4];
+  f32x4 acc[FI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (K + BK - 1) / BK;      // a ragged K tail is staged from the zero page
-  stage_tile<A_KC>(A, lda, m0, M, 0, K, smem, wave, lane);
+  stage_tile<A_KC, MT / 32>(A, lda, m0, M, 0, K, smem, wave, lane);
   stage_tile<B_KC>(B, ldb, n0, N, 0, K, smem + TILE_BYTES, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -364,16 +370,16 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
     char* sb = sa + TILE_BYTES;
     if (kt + 1 < nk) {
       char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile<A_KC>(A, lda, m0, M, (kt + 1) * BK, K, na, wave, lane);
+      stage_tile<A_KC, MT / 32>(A, lda, m0, M, (kt + 1) * BK, K, na, wave, lane);
       stage_tile<B_KC>(B, ldb, n0, N, (kt + 1) * BK, K, na + TILE_BYTES, wave, lane);
     }
     // both k-halves' fragments are read up front (the second half lands under the first half's MFMAs), and the
     // MFMA bursts run at raised priority so the co-resident workgroup's loads do not break them up
-    bf16x8 fa[2][4], fb[2][4];
+    bf16x8 fa[2][FI], fb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag<A_KC>(sa, wm * 64 + i * 16, kk, lane);
+      for (int i = 0; i < FI; ++i) fa[kk][i] = read_frag<A_KC>(sa, wm * (MT / 2) + i * 16, kk, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[kk][j] = read_frag<B_KC>(sb, wn * 64 + j * 16, kk, lane);
     }
@@ -381,7 +387,7 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
@@ -393,8 +399,8 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
 
   // D[i = n][j = m]: lane holds m = lane&15, n = 4*(lane>>4) + r
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < FI; ++i) {
+    const int m = m0 + wm * (MT / 2) + i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
@@ -403,12 +409,12 @@ __device__ __forceinline__ void gemm128_tile(const bf16_t* __restrict__ A, const
   }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int MT = 128>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          int M, int N, int K, int lda, int ldb, int tiles_m,
                                                          int tiles_n, Epi epi) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
-  gemm128_tile<A_KC, B_KC>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+  gemm128_tile<A_KC, B_KC, MT>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
 }
 
 // Grouped launch: up to O2_GEMM_MAX_GROUP independent problems of one operand form share a grid, so the tail
@@ -1306,6 +1312,7 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   int tile = a->tile_hint;
   if (tile == 257 || tile == 258) tile = 256;       // hints of the round-2 A/B tools: the same kernel
+  if (tile == 64) tile = 128;                         // the 128-wide kernel on 64-row tiles (see the dispatch at the end)
   if (tile != 128 && tile != 256 && tile != 260 && tile != 261 && tile != 262) {
     // measured on MI355X (tools/gemm_p8_ab.py, tools/gemm_t8_ab.py, tools/gemm_w4_ab.py; profiles/r02_gemm_*, r03_gemm_w4_*): a
     // 256-tile kernel wins in every operand form whenever its tiles fill the chip -- the 4-wave kernel on whole tiles
@@ -1380,7 +1387,24 @@ extern "C" int orbit2_gemm_bf16(const orbit2_gemm_args* a, void* stream) {
     O2_CHECK_LAUNCH();
     return O2_OK;
   }
-  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+  int tiles_m = (a->M + BM - 1) / BM;
+  const int tiles_n = (a->N + BN - 1) / BN;
+  // fewer 128 x 128 tiles than two per CU and a K-contiguous A: 64-row tiles, so that every CU still holds two workgroups
+  // (hint 64 forces them, hint 128 forbids them)
+  if (a->tile_hint == 64 && !a->a_kc) return O2_ERR_ARG;
+  const bool half_rows = a->a_kc && (a->tile_hint == 64 || (a->tile_hint != 128 && (long)tiles_m * tiles_n < 2 * 256 && a->M > 64));
+  if (half_rows) {
+    tiles_m = (a->M + 63) / 64;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    if (a->b_kc)
+      hipLaunchKernelGGL((gemm128_kernel<true, true, 64>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb, tiles_m,
+                         tiles_n, e);
+    else
+      hipLaunchKernelGGL((gemm128_kernel<true, false, 64>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb, tiles_m,
+                         tiles_n, e);
+    O2_CHECK_LAUNCH();
+    return O2_OK;
+  }
   dim3 grid(tiles_m * tiles_n), block(256);
   if (a->a_kc && a->b_kc)
     hipLaunchKernelGGL((gemm128_kernel<true, true>), grid, block, 0, s, A, B, a->M, a->N, a->K, a->lda, a->ldb,

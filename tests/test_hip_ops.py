@@ -236,6 +236,30 @@ def test_gemm_single_round_grids(hip, name, N, K, form):
     mask, sc = keep_mask(11, M * N, 0.1)
     want = (A @ B.t() + bias.float().cpu()) * torch.from_numpy(mask).view(M, N) * sc
     assert nerr(o, want) < 6e-3
+    # as dispatched these grids run on 64-ROW tiles (two workgroups per CU, round 5): the same bits as the 128 x 128 tiles
+    o128, o64 = torch.empty_like(o), torch.empty_like(o)
+    hip.gemm(Ad, Bd, o128, M, N, K, K, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, bias=bias, drop_p=0.1, seed=11, tile=128)
+    hip.gemm(Ad, Bd, o64, M, N, K, K, K if b_kc else N, N, a_kc=a_kc, b_kc=b_kc, bias=bias, drop_p=0.1, seed=11, tile=64)
+    assert torch.equal(o, o64) and torch.equal(o64, o128)
+
+
+@pytest.mark.parametrize("M,N,K,b_kc", [(64, 128, 64, True), (72, 136, 200, True), (1000, 384, 200, False), (130, 128, 128, False)])
+def test_gemm_64_row_tiles_ragged(hip, M, N, K, b_kc):
+    """tile hint 64 on ragged shapes: rows clamped at M, nothing written past them, bits equal to the 128 x 128 tiles"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = rt(torch.randn(M, K, generator=g)), rt(torch.randn(N, K, generator=g))
+    Ad, Bd = bf(A).cuda(), bf(B if b_kc else B.t().contiguous()).cuda()
+    res = bf(torch.randn(M, N, generator=g)).cuda()
+    outs = []
+    for tile in (128, 64):
+        guard = torch.full((M + 70, N), 7.0, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(Ad, Bd, guard, M, N, K, K, K if b_kc else N, N, a_kc=True, b_kc=b_kc, act=1, residual=res, ldr=N, tile=tile)
+        assert torch.all(guard[M:] == 7.0)
+        outs.append(guard[:M].clone())
+    assert torch.equal(outs[0], outs[1])
+    assert nerr(outs[1], F.gelu(A @ B.t()) + res.float().cpu()) < 8e-3
+    with pytest.raises(Exception):                          # the 64-row tile exists for a K-contiguous A only
+        hip.gemm(bf(A.t().contiguous()).cuda(), Bd, guard, M, N, K, M + (-M) % 8, K if b_kc else N, N, a_kc=False, b_kc=b_kc, tile=64)
 
 
 @pytest.mark.parametrize("form,K", [("tn", 70), ("tn", 201), ("tn", 64 + 35), ("nt", 72), ("nn", 136), ("tt", 40)])
