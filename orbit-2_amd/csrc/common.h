@@ -165,9 +165,16 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 // the error of this factor goes un-averaged into the residual-gradient stream (tests/test_model_gpu.py: pos_embed).
 // pack_q14 SATURATES at the ends of [-2, 2): a factor outside it (GELU' up to 1.13 x a dropout scale >= 1.77, i.e. drop_p >= 0.434 --
 // rejected by gemm_make_epi) must never wrap to the opposite sign.
+// Round-to-nearest-even and the saturation without an integer conversion: x * 2^14 + 1.5 * 2^23 is exact up to the one rounding at
+// ulp = 1 (the scaling is a power of two), which leaves the integer, two's complement, in the low mantissa bits; clamping the SUM to
+// [magic - 32768, magic + 32767] saturates it (the bounds are integers: clamp and rounding commute), and one byte permute packs the
+// two low halves.  Same bits as  min(max(rint(x * 16384), -32768), 32767)  for every finite x (NaN packs as 0x8000... never produced:
+// the factor is bounded); 2.5 vector instructions per value instead of 5.5 in the GELU epilogue that is bound by them.
 __device__ __forceinline__ unsigned pack_q14(float lo, float hi) {
-  const int a = min(max(__float2int_rn(lo * 16384.f), -32768), 32767), b = min(max(__float2int_rn(hi * 16384.f), -32768), 32767);
-  return ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+  constexpr float MAGIC = 12582912.0f;                 // 1.5 * 2^23 = 0x4B400000: low 16 bits zero
+  const float a = __builtin_amdgcn_fmed3f(fmaf(lo, 16384.f, MAGIC), MAGIC - 32768.f, MAGIC + 32767.f);
+  const float b = __builtin_amdgcn_fmed3f(fmaf(hi, 16384.f, MAGIC), MAGIC - 32768.f, MAGIC + 32767.f);
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x05040100u);   // b.lo16 : a.lo16
 }
 __device__ __forceinline__ void unpack_q14(unsigned w, float& lo, float& hi) {
   lo = (float)(int)(short)(w & 0xffffu) * (1.0f / 16384.f);

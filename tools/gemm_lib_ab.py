@@ -25,7 +25,9 @@ g = torch.Generator(device="cuda").manual_seed(1)
 rnd = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.5).to(BF)
 cases = []
 for name, N, K, kw in [("qkv fwd (bias)", 3 * D, D, dict(bias=True)), ("proj fwd (bias+drop+res)", D, D, dict(bias=True, drop_p=0.1, residual=True)),
-                       ("fc1 fwd (bias+gelu+drop)", 4 * D, D, dict(bias=True, act=1, drop_p=0.1, save_pre=True)), ("fc2 fwd (bias+drop+res)", D, 4 * D, dict(bias=True, drop_p=0.1, residual=True))]:
+                       ("fc1 fwd (bias+gelu+drop)", 4 * D, D, dict(bias=True, act=1, drop_p=0.1, save_pre=True)),
+                       ("fc1 fwd kind 1 (+factor)", 4 * D, D, dict(bias=True, act=1, drop_p=0.1, save_dact=True)),
+                       ("fc2 fwd (bias+drop+res)", D, 4 * D, dict(bias=True, drop_p=0.1, residual=True))]:
     cases.append((name, "nt", N, K, kw))
 for name, N, K in [("dX qkv (NN)", D, 3 * D), ("dX fc1 (NN)", D, 4 * D), ("dX fc2 (NN)", 4 * D, D)]:
     cases.append((name, "nn", N, K, {}))
@@ -37,16 +39,18 @@ for name, kind, N, K, kw in cases:
     outs = {}
     def call(lib, out, pre):
         a = _hip.GemmArgs()
-        k2 = dict(kw); k2.pop("bias", None); k2.pop("residual", None); k2.pop("save_pre", None)
+        k2 = dict(kw); k2.pop("bias", None); k2.pop("residual", None); k2.pop("save_pre", None); k2.pop("save_dact", None)
         _hip._gemm_fill(a, x, w, out, M, N, K, K, K if kind == "nt" else N, N, a_kc=True, b_kc=(kind == "nt"), bias=bias,
-                        residual=res, ldr=N if res is not None else 0, save_pre=pre, seed=5, **k2)
+                        residual=res, ldr=N if res is not None else 0, save_pre=pre if kw.get("save_pre") else None,
+                        save_dact=pre if kw.get("save_dact") else None, seed=5, **k2)
         assert lib.orbit2_gemm_bf16(C.byref(a), S()) == 0
     tm = {k: [] for k in libs}
     for k, lib in libs.items():
-        outs[k] = (torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, N, dtype=BF, device="cuda") if kw.get("save_pre") else None)
+        side = torch.empty(M, N, dtype=BF, device="cuda") if kw.get("save_pre") else (torch.empty(M, N, dtype=torch.int16, device="cuda") if kw.get("save_dact") else None)
+        outs[k] = (torch.empty(M, N, dtype=BF, device="cuda"), side)
         call(lib, *outs[k])
     torch.cuda.synchronize()
-    same = torch.equal(outs["tree"][0], outs["alt"][0]) if check else None
+    same = (torch.equal(outs["tree"][0], outs["alt"][0]) and (outs["tree"][1] is None or torch.equal(outs["tree"][1], outs["alt"][1]))) if check else None
     for r in range(5):
         for k, lib in libs.items():
             tm[k].append(t(lambda: call(lib, *outs[k])))

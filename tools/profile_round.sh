@@ -1,7 +1,7 @@
 set -e
 # usage (on the GPU box): bash tools/profile_round.sh [tag]  -- rocprofv3 passes of the default bench configuration
 # (kernel stats; FETCH_SIZE; WRITE_SIZE; MFMA-busy + clock; optional DRAM/MALL counters when the box lists them)
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof
