@@ -84,7 +84,6 @@ def traffic(fetch_csv, write_csv, out):
                     "is L2-miss traffic (Infinity-Cache hits included)")
     res["_config"] = {"model": "interm_1b", "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 8, "grid": "128x256"}
     # the build the counters belong to: bench.py uses this file only for a library with the same source hash
-    import os
     sh = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "orbit-2_amd", "lib", "liborbit2_hip.so.srchash")
     res["_srchash"] = open(sh).read().strip() if os.path.exists(sh) else None
     json.dump(res, open(out, "w"), indent=1)
