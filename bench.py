@@ -344,7 +344,7 @@ def main():
     tp = a.tensor_par
     capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
     # (the parameter-sharding engine stays eager: capturing its cross-stream gather / release pattern was tried in round 3 and
-    #  hipStreamEndCapture crashes on it -- DESIGN 6c)
+    #  hipStreamEndCapture crashes on it -- DESIGN 5)
     if a.fsdp and a.graph == "on":
         raise SystemExit("--fsdp runs without hipGraph replay")
     a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable and not a.fsdp)

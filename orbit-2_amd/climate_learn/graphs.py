@@ -26,7 +26,7 @@ SALT_STEP = 0x9E3779B97F4A7C15       # odd: the salt walks through all 2^64 valu
 # capture is open invalidates the capture -- and the call itself fails.  A process that has an RCCL process group has such a
 # thread: ProcessGroupNCCL's watchdog polls hipEventQuery on the end events of every collective it still tracks (the warm-up
 # passes' bucket all-reduces); when its query lands inside a global-mode capture it gets hipErrorStreamCaptureUnsupported, throws
-# from a non-Python thread, and the process ends in std::terminate -> SIGABRT (round 4's driver run).  Whether it lands
+# from a non-Python thread, and the process ends in std::terminate -> SIGABRT (round 4's driver run; DESIGN 2, "GPU suite hygiene").  Whether it lands
 # there is a race against its 100 ms poll.  "thread_local" restricts the check to the capturing thread.  That is safe for this
 # body because everything the capture must not see is already excluded by construction: every kernel of the step is launched
 # from THIS thread on the capturing stream or on the engine's communication stream forked from it by an event recorded inside
@@ -58,7 +58,7 @@ class GraphedTrainStep:
             # The parameter-sharding engine is eager-only.  Its step does record into a capture (per-unit all-gathers, pooled
             # buffers, reduce-scatters, cross-stream hand-over events), but hipStreamEndCapture then segfaults inside the runtime
             # -- in round 3, and again in round 5 with every pool event of the uncaptured warm-up forgotten before the capture so
-            # that each wait followed a record made inside it (DESIGN 6c).  It exists for models whose parameters do not fit a
+            # that each wait followed a record made inside it (DESIGN 5).  It exists for models whose parameters do not fit a
             # GPU replicated; those are not launch-bound, which is all a replayed graph buys.
             raise NotImplementedError("GraphedTrainStep: the parameter-sharding engine (HipFullyShardedDataParallel) runs eagerly; "
                                       "use HipDataParallel (optionally shard_optimizer=True) for a captured step")
@@ -87,7 +87,7 @@ class GraphedTrainStep:
         from . import _ops
         # CommStats records timing-enabled events on the capturing streams and reads them back with elapsed_time: a captured event
         # has no timestamp (querying it is invalid), and round 3's segfault in hipStreamEndCapture happened with exactly this
-        # combination on the path -- refuse it instead of handing it to the runtime
+        # combination on the path (profiles/HISTORY_r01_r04.md 6c) -- refuse it instead of handing it to the runtime
         if getattr(self.engine, "comm_stats", None) is not None and not getattr(self, "_allow_comm_stats", False):
             raise RuntimeError("GraphedTrainStep: engine.comm_stats is set -- communication accounting uses timing events and "
                                "cannot run inside a hipGraph capture; unset it (or run the step eagerly)")

@@ -168,7 +168,7 @@ def child_fully_sharded_engine_matches_replicated_engine(golden_dir):
 
 
 def test_graphed_step_refuses_the_parameter_sharding_engine(golden_dir):
-    """the FULL_SHARD engine is eager-only (its capture crashes in hipStreamEndCapture, DESIGN 6c): asking for a captured step
+    """the FULL_SHARD engine is eager-only (its capture crashes in hipStreamEndCapture, DESIGN 5): asking for a captured step
     is an error at construction, not a crash at capture"""
     import torch.nn as nn
     import climate_learn as cl
