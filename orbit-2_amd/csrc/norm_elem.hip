@@ -287,7 +287,18 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   float s = 0.f;
   if (e < 2 * D) {
     const int which = e / D, col = e - which * D;
-    for (int p = ty; p < nblk; p += 8) s += part[((size_t)p * 2 + which) * D + col];
+    // eight partial rows in flight per thread (one dependent add chain per row kept the launch at 0.5 TB/s: 100 us for
+    // 50 MB at the interm_1b shape); fixed order: the eight chains, then their tree
+    const float* src = part + (size_t)which * D + col;
+    const size_t step = (size_t)2 * D;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = ty;
+    for (; p + 56 < nblk; p += 64) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += src[(size_t)(p + 8 * k) * step];
+    }
+    for (int k = 0; p < nblk; p += 8, ++k) a[k] += src[(size_t)p * step];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   red[ty][tx] = s;
   __syncthreads();
@@ -492,8 +503,17 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + tx;
   float s = 0.f;
-  if (col < N)
-    for (int p = ty; p < P; p += 8) s += part[(size_t)p * N + col];
+  if (col < N) {
+    const float* src = part + col;           // eight partial rows in flight per thread, fixed order (see ln_bwd_reduce_kernel)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = ty;
+    for (; p + 56 < P; p += 64) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += src[(size_t)(p + 8 * k) * N];
+    }
+    for (int k = 0; p < P; p += 8, ++k) a[k] += src[(size_t)p * N];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && col < N) {
