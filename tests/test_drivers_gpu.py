@@ -347,7 +347,7 @@ def test_bench_single_rank_line_with_baselines(tmp_path):
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["unit"] == "TFLOP/s"
     # the step's figure: executed FLOPs per step / step time (one "launch" = one step), the GEMM family beside it
     assert abs(rf["achieved"] * 1e12 - rf["algorithmic_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3)) < 1e-6 * rf["achieved"] * 1e12
-    assert abs(rf["frac"] - d["step_model"]["mfma_frac_of_peak_executed"]) < 1e-12 and d["roofline_gemm"]["frac"] >= rf["frac"]
+    assert abs(rf["frac"] - d["step_model"]["mfma_frac_of_peak_executed"]) < 1e-12 and 0 < d["roofline_gemm"]["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     ge = d["gpu_eager_baseline"]

@@ -248,3 +248,4 @@ def test_committed_bf16_spreads_belong_to_the_seeded_cases(golden_dir):
         e_pred, e_loss, e_grad = z[name + "/oracle_vs_reference_fp32"]
         assert e_pred < 1e-4 and e_loss < 1e-5 and e_grad < 2e-3, (name, e_pred, e_loss, e_grad)
     assert H.grad_tolerance(0.0) == 2e-2 and H.grad_tolerance(0.05) == pytest.approx(0.075) and H.grad_tolerance(0.5) == 0.15
+    assert H.grad_tolerance(0.27, stress=True) == pytest.approx(0.32) and H.grad_tolerance(0.05, stress=True) == pytest.approx(0.075)
