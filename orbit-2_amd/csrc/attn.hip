@@ -129,6 +129,9 @@ __device__ __forceinline__ void attn_tile_coords(int nq, int H, int& qt, int& he
 // half the LDS-DMA pieces per wave and per MFMA of the 4-wave / two-workgroups-per-CU form (the stamps of that form,
 // profiles/r02_attn_fwd_stamps_4wave.txt, show 8 pieces per wave and tile costing 700-970 of ~3200-5100 cycles: the CU's
 // LDS write path is busy ~11 cycles per 1-KiB piece and all 8 resident waves queue on it).
+#ifndef O2_FWD256_LA
+#define O2_FWD256_LA 3
+#endif
 template <int D, bool DROP, bool RAGGED, int NW>
 __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float sc_log2,
@@ -193,11 +196,35 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
     // the two key blocks' chains are interleaved: a K fragment is consumed two MFMAs after the previous one of its
     // chain, so its LDS read has twice the time to land
+    if constexpr (D == 256) {
+      // one wave per SIMD (512 registers): nobody else covers an LDS read's latency, and left alone hipcc puts `s_waitcnt
+      // lgkmcnt(0)` between every fragment read and its MFMA (64 exposed LDS latencies per tile: the kernel ran at 0.24 of the
+      // MFMA peak).  O2_FWD256_LA fragments in flight ahead of the MFMA that consumes them, the order pinned (the discipline of
+      // attn_bwd_dkv256_kernel); same products in the same order: the same bits.
+      constexpr int LA = O2_FWD256_LA;      // k-steps ahead: 2 LA fragments (both key blocks of a k-step) in flight
+      bf16x8 k0[LA + 1], k1[LA + 1];
 #pragma unroll
-    for (int ds = 0; ds < C::NDS; ++ds)
+      for (int i = 0; i < LA; ++i) {
+        k0[i] = row_frag<D>(sk, (lane & 31), i, hq);
+        k1[i] = row_frag<D>(sk, 32 + (lane & 31), i, hq);
+      }
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s[kb]);
+      for (int ds = 0; ds < C::NDS; ++ds) {
+        if (ds + LA < C::NDS) {
+          k0[(ds + LA) % (LA + 1)] = row_frag<D>(sk, (lane & 31), ds + LA, hq);
+          k1[(ds + LA) % (LA + 1)] = row_frag<D>(sk, 32 + (lane & 31), ds + LA, hq);
+        }
+        s[0] = MFMA32(k0[ds % (LA + 1)], qf[ds], s[0]);
+        s[1] = MFMA32(k1[ds % (LA + 1)], qf[ds], s[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], s[kb]);
+    }
     if (RAGGED && t == nt - 1 && (L & 63)) {   // keys past the end of a ragged sequence get no weight
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -245,15 +272,32 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_kernel(c
     }
     O2_SEG(tSM)
     // O^T[db] += V^T . P^T
+    if constexpr (D == 256) {
+      bf16x8 pf[4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int g = 0; g < 4; ++g) pf[g] = pack_frag(s[g >> 1], g & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int NV = 4 * C::NDB, LA = O2_FWD256_LA;      // fragment i: key group (kb, ss) = i / NDB, d block i % NDB
+      bf16x8 vr[LA + 1];
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = pack_frag(s[kb], ss);
+      for (int i = 0; i < LA; ++i) vr[i] = tr_frag<D>(sv, (i / C::NDB) * 16, i % C::NDB, lane);
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-          o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
+      for (int i = 0; i < NV; ++i) {
+        if (i + LA < NV) vr[(i + LA) % (LA + 1)] = tr_frag<D>(sv, ((i + LA) / C::NDB) * 16, (i + LA) % C::NDB, lane);
+        o[i % C::NDB] = MFMA32(vr[i % (LA + 1)], pf[i / C::NDB], o[i % C::NDB]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 pf = pack_frag(s[kb], ss);
+#pragma unroll
+          for (int db = 0; db < C::NDB; ++db)
+            o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
+        }
+    }
     O2_SEG(tPV)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     O2_SEG(tW)
@@ -365,11 +409,31 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
   // `init` (16 registers, all = -reference) is the C operand of both chains' first MFMA and stays live: no per-tile
   // accumulator initialisation.
   auto scores = [&](const char* sk, int t, const f32x16& init, f32x16 (&s)[2]) {
+    if constexpr (D == 256) {             // one wave per SIMD: fragments in flight ahead of their MFMAs, pinned (see attn_fwd_kernel)
+      constexpr int LA = O2_FWD256_LA;
+      bf16x8 k0[LA + 1], k1[LA + 1];
 #pragma unroll
-    for (int ds = 0; ds < C::NDS; ++ds)
+      for (int i = 0; i < LA; ++i) {
+        k0[i] = row_frag<D>(sk, (lane & 31), i, hq);
+        k1[i] = row_frag<D>(sk, 32 + (lane & 31), i, hq);
+      }
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], ds == 0 ? init : s[kb]);
+      for (int ds = 0; ds < C::NDS; ++ds) {
+        if (ds + LA < C::NDS) {
+          k0[(ds + LA) % (LA + 1)] = row_frag<D>(sk, (lane & 31), ds + LA, hq);
+          k1[(ds + LA) % (LA + 1)] = row_frag<D>(sk, 32 + (lane & 31), ds + LA, hq);
+        }
+        s[0] = MFMA32(k0[ds % (LA + 1)], qf[ds], ds == 0 ? init : s[0]);
+        s[1] = MFMA32(k1[ds % (LA + 1)], qf[ds], ds == 0 ? init : s[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int ds = 0; ds < C::NDS; ++ds)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          s[kb] = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], ds == 0 ? init : s[kb]);
+    }
     if (RAGGED && t == nt - 1 && (L & 63)) {   // keys past the end of a ragged sequence get no weight
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -405,15 +469,32 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_fwd_lazy_ker
         drop_keys_in_regs<true>(s[kb], rowhash, *reinterpret_cast<const u32x4*>(&skh[cur][(t % KT) * 16 + hq * 8 + kb * 4]), thr);
     }
     O2_SEG(tSM)
+    if constexpr (D == 256) {
+      bf16x8 pf[4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int g = 0; g < 4; ++g) pf[g] = pack_frag(s[g >> 1], g & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int NV = 4 * C::NDB, LA = O2_FWD256_LA;
+      bf16x8 vr[LA + 1];
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = pack_frag(s[kb], ss);
+      for (int i = 0; i < LA; ++i) vr[i] = tr_frag<D>(sv, (i / C::NDB) * 16, i % C::NDB, lane);
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-          o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
+      for (int i = 0; i < NV; ++i) {
+        if (i + LA < NV) vr[(i + LA) % (LA + 1)] = tr_frag<D>(sv, ((i + LA) / C::NDB) * 16, (i + LA) % C::NDB, lane);
+        o[i % C::NDB] = MFMA32(vr[i % (LA + 1)], pf[i / C::NDB], o[i % C::NDB]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 pf = pack_frag(s[kb], ss);
+#pragma unroll
+          for (int db = 0; db < C::NDB; ++db)
+            o[db] = MFMA32(tr_frag<D>(sv, kb * 32 + ss * 16, db, lane), pf, o[db]);
+        }
+    }
     O2_SEG(tPV)
     if (t % KT == KT - 1 || t == nt - 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -706,10 +787,30 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, dp;
+      if constexpr (D == 256) {       // one wave per SIMD: O2_FWD256_LA k-steps of K / V fragments in flight, pinned (see attn_fwd_kernel)
+        constexpr int LA = O2_FWD256_LA;
+        bf16x8 kr[LA + 1], vr[LA + 1];
 #pragma unroll
-      for (int ds = 0; ds < C::NDS; ++ds) {
-        s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], ds == 0 ? nlse : s);
-        dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], ds == 0 ? ndlt : dp);
+        for (int i = 0; i < LA; ++i) {
+          kr[i] = row_frag<D>(sk, kb * 32 + (lane & 31), i, hq);
+          vr[i] = row_frag<D>(sv, kb * 32 + (lane & 31), i, hq);
+        }
+#pragma unroll
+        for (int ds = 0; ds < C::NDS; ++ds) {
+          if (ds + LA < C::NDS) {
+            kr[(ds + LA) % (LA + 1)] = row_frag<D>(sk, kb * 32 + (lane & 31), ds + LA, hq);
+            vr[(ds + LA) % (LA + 1)] = row_frag<D>(sv, kb * 32 + (lane & 31), ds + LA, hq);
+          }
+          s = MFMA32(kr[ds % (LA + 1)], qf[ds], ds == 0 ? nlse : s);
+          dp = MFMA32(vr[ds % (LA + 1)], dof[ds], ds == 0 ? ndlt : dp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int ds = 0; ds < C::NDS; ++ds) {
+          s = MFMA32(row_frag<D>(sk, kb * 32 + (lane & 31), ds, hq), qf[ds], ds == 0 ? nlse : s);
+          dp = MFMA32(row_frag<D>(sv, kb * 32 + (lane & 31), ds, hq), dof[ds], ds == 0 ? ndlt : dp);
+        }
       }
       // a dropped element: (0 - delta) instead of (dP - delta)
       if (DROP)
@@ -722,12 +823,29 @@ __global__ __launch_bounds__(NW * 64, (D == 256 ? 1 : 2)) void attn_bwd_dq_kerne
         if (tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq >= L) p = 0.f;   // key past the end
         s[r] = DLT_INIT ? p * dp[r] : p * (dp[r] - dlt);  // dS^T
       }
+      if constexpr (D == 256) {
+        bf16x8 dsf[2];
+        dsf[0] = pack_frag(s, 0);
+        dsf[1] = pack_frag(s, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NV = 2 * C::NDB, LA = O2_FWD256_LA;
+        bf16x8 tr[LA + 1];
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 dsf = pack_frag(s, ss);
+        for (int i = 0; i < LA; ++i) tr[i] = tr_frag<D>(sk, kb * 32 + (i / C::NDB) * 16, i % C::NDB, lane);
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-          dq[db] = MFMA32(tr_frag<D>(sk, kb * 32 + ss * 16, db, lane), dsf, dq[db]);
+        for (int i = 0; i < NV; ++i) {
+          if (i + LA < NV) tr[(i + LA) % (LA + 1)] = tr_frag<D>(sk, kb * 32 + ((i + LA) / C::NDB) * 16, (i + LA) % C::NDB, lane);
+          dq[i % C::NDB] = MFMA32(tr[i % (LA + 1)], dsf[i / C::NDB], dq[i % C::NDB]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 dsf = pack_frag(s, ss);
+#pragma unroll
+          for (int db = 0; db < C::NDB; ++db)
+            dq[db] = MFMA32(tr_frag<D>(sk, kb * 32 + ss * 16, db, lane), dsf, dq[db]);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
