@@ -401,15 +401,18 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restri
 }
 
 // ---- column sums: stage 1 partials [P][N] (16-byte loads, 8 row-lanes per block), stage 2 reduce ----------
-constexpr int CS_ROWS = 128;
+// rows per partial sum: 128 for the large problems; 32 when there are few rows (the 32 x 64-grid presets: 4096 rows x 1024 columns
+// were 128 workgroups walking 16 rows each one after the other -- half the CUs, latency-bound; 512 workgroups of 4 rows now).
+// One function decides for the workspace query and both launchers.
+static inline int cs_rows(int M) { return M >= 32768 ? 128 : 32; }
 template <bool FP32>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict__ xv, int M, int N, int ldx,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, int rpp) {
   __shared__ float red[8][32][9];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = (blockIdx.x * 32 + tx) * 8;
-  const int r0 = blockIdx.y * CS_ROWS;
-  const int r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  const int r0 = blockIdx.y * rpp;
+  const int r1 = r0 + rpp < M ? r0 + rpp : M;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < N) {
     if (FP32) {
@@ -449,12 +452,12 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict
 __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dym,
                                                                  int M, int N, unsigned thr, float dscale, uint64_t seed,
                                                                  const float* __restrict__ rowscale, int rows_per_scale,
-                                                                 float* __restrict__ part) {
+                                                                 float* __restrict__ part, int rpp) {
   __shared__ float red[8][32][9];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = (blockIdx.x * 32 + tx) * 8;
-  const int r0 = blockIdx.y * CS_ROWS;
-  const int r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  const int r0 = blockIdx.y * rpp;
+  const int r1 = r0 + rpp < M ? r0 + rpp : M;
   const uint64_t sd = seed ^ o2_seed_salt;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < N) {
@@ -699,7 +702,15 @@ extern "C" int orbit2_layernorm_fwd_ld(const void* x, const void* gamma, const v
 }
 
 static inline int ln_bwd_nparts(int rows) { return ((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)) * 4; }
-extern "C" int orbit2_layernorm_bwd_ws_floats(int rows, int D) { return ln_bwd_nparts(rows) * 2 * D; }
+// few rows (the 32 x 64-grid presets): LN_FEW_RPB rows per workgroup of the row-shared form -- 4096 rows at 16 per workgroup were
+// 256 workgroups of two waves walking their rows one global-load latency after the other (18 us at D = 1024, a quarter of it
+// bandwidth); 4 per workgroup put four workgroups on every CU
+constexpr int LN_FEW_RPB = 4;
+static inline int ln_bwd_nparts_few(int rows) { return (rows + LN_FEW_RPB - 1) / LN_FEW_RPB; }
+extern "C" int orbit2_layernorm_bwd_ws_floats(int rows, int D) {
+  const int a = ln_bwd_nparts(rows), b = rows < 32768 ? ln_bwd_nparts_few(rows) : 0;
+  return (a > b ? a : b) * 2 * D;
+}
 
 extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
                                     const float* rstd, const void* dres, void* dx, void* dgamma, void* dbeta,
@@ -708,17 +719,17 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws) return O2_ERR_ARG;
   if (rows <= 0 || (D & 7) || D > LN_MAXD) return O2_ERR_ARG;
   const int nparts = ln_bwd_nparts(rows);
-  if (ws_floats < nparts * 2 * D) return O2_ERR_ARG;
+  if (ws_floats < orbit2_layernorm_bwd_ws_floats(rows, D)) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nc = (D / 8 + 63) / 64;
-  // row-shared form for the model widths (8m / 117m / 1b / 10b); 64 rows per block, 16 when there are few rows (the
+  // row-shared form for the model widths (8m / 117m / 1b / 10b); 64 rows per block, LN_FEW_RPB when there are few rows (the
   // small grids: 4096 rows would otherwise occupy 64 CUs).  The workspace holds 4 partial rows per 64 input rows.
   const bool few = rows < 32768;
-  const int npart_used = few ? (rows + 15) / 16 : nparts / 4;
+  const int npart_used = few ? ln_bwd_nparts_few(rows) : nparts / 4;
 #define WIDE(NCW, TPB)                                                                                              \
   do {                                                                                                              \
     if (few)                                                                                                        \
-      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, 16>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,   \
+      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, LN_FEW_RPB>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,   \
                          (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws,  \
                          rows, D);                                                                                  \
     else                                                                                                            \
@@ -777,18 +788,18 @@ extern "C" int orbit2_post_reduce(const void* x, const void* addend, int res_mod
   return O2_OK;
 }
 
-extern "C" int orbit2_colsum_ws_floats(int M, int N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N; }
+extern "C" int orbit2_colsum_ws_floats(int M, int N) { return ((M + cs_rows(M) - 1) / cs_rows(M)) * N; }
 
 extern "C" int orbit2_colsum(const void* x, int x_fp32, int M, int N, int ldx, void* out, int out_fp32, float beta,
                              float* ws, int ws_floats, void* stream) {
   if (!x || !out || !ws || M <= 0 || N <= 0) return O2_ERR_ARG;
-  const int P = (M + CS_ROWS - 1) / CS_ROWS;
+  const int rpp = cs_rows(M), P = (M + rpp - 1) / rpp;
   if (ws_floats < P * N) return O2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if ((N & 7) || (ldx & 7)) return O2_ERR_ARG;
   dim3 g1((N + 255) / 256, P);
-  if (x_fp32) hipLaunchKernelGGL(colsum_part_kernel<true>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
-  else hipLaunchKernelGGL(colsum_part_kernel<false>, g1, dim3(256), 0, s, x, M, N, ldx, ws);
+  if (x_fp32) hipLaunchKernelGGL(colsum_part_kernel<true>, g1, dim3(256), 0, s, x, M, N, ldx, ws, rpp);
+  else hipLaunchKernelGGL(colsum_part_kernel<false>, g1, dim3(256), 0, s, x, M, N, ldx, ws, rpp);
   O2_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, ws, P, N, out, out_fp32, beta);
   O2_CHECK_LAUNCH();
@@ -800,12 +811,12 @@ extern "C" int orbit2_dropout_bwd_colsum(const void* dy, void* dym, int M, int N
                                          float* ws, int ws_floats, void* stream) {
   if (!dy || !dym || !colsum_out || !ws || M <= 0 || N <= 0 || (N & 7)) return O2_ERR_ARG;
   if (drop_p < 0.f || drop_p >= 1.f || (rowscale && rows_per_scale <= 0)) return O2_ERR_ARG;
-  const int P = (M + CS_ROWS - 1) / CS_ROWS;
+  const int rpp = cs_rows(M), P = (M + rpp - 1) / rpp;
   if (ws_floats < P * N) return O2_ERR_ARG;
   const unsigned thr = (unsigned)(drop_p * 256.0f + 0.5f);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3((N + 255) / 256, P), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dym, M, N,
-                     thr, 256.0f / (256.0f - (float)thr), seed, rowscale, rows_per_scale, ws);
+                     thr, 256.0f / (256.0f - (float)thr), seed, rowscale, rows_per_scale, ws, rpp);
   O2_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, ws, P, N, colsum_out, out_fp32, beta);
   O2_CHECK_LAUNCH();
