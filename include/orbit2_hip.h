@@ -160,6 +160,15 @@ int orbit2_varagg_fwd(const float* x, const float* stab, const float* gtab, void
 int64_t orbit2_varagg_bwd_ws_floats(int B, int V, int h, int w, int H, int D);
 int orbit2_varagg_bwd(const float* x, const float* gtab, const float* attw, const void* dz, float* dstab,
                       float* dgtab, int B, int V, int h, int w, int H, int D, float* ws, void* stream);
+/* The per-variable rows both tables are built from (ABI 6): cmat[(v, c)][D], c = 0..3 = the 2x2 patch-embed weight of variable
+ * ids[v] transposed ([D][4] -> 4 rows), c = 4 = its bias + var_embed[ids[v]]  (res_slimvit.py:64-66 PatchEmbed x V, :182-201
+ * var-embed gather, :251-262).  The V_total per-variable parameters are addressed as base + index * stride (elements): a caller
+ * whose parameters lie at a uniform pitch (a flat parameter buffer) builds the rows in one launch; _scatter is the transpose and
+ * ACCUMULATES into the gradient buffers at the same pitches (ids distinct). */
+int orbit2_tables_gather(const float* w_base, int64_t w_stride, const float* b_base, int64_t b_stride, const float* var_embed,
+                         const int* ids, float* cmat, int V, int D, void* stream);
+int orbit2_tables_scatter(const float* dcmat, float* dw_base, int64_t w_stride, float* db_base, int64_t b_stride,
+                          float* dvar_embed, const int* ids, int V, int D, void* stream);
 /* 1 if orbit2_varagg_bwd sums the table gradients in a fixed order for this shape (bitwise reproducible), 0 if it takes the
  * scalar fallback that accumulates them with fp32 atomics (head dim not 64 / 128 / 256, 5 V > 128, ORBIT2_VARAGG_SCALAR set):
  * callers that keep replicas of the tables in lock-step without exchanging gradients need to know (dist/tp.py ReplicaGuard) */

@@ -348,6 +348,23 @@ def varagg_bwd(x, gtab, attw, dz, H, D):
     return dstab, dgtab
 
 
+def tables_gather(w0, w_stride, b0, b_stride, var_embed, ids, V, D):
+    """cmat [5 V, D] fp32 from the per-variable patch-embed parameters laid out at a uniform pitch (w0 / b0 = parameter 0)"""
+    _dev(w0, F32, "token_embeds.0.proj.weight"); _dev(b0, F32, "token_embeds.0.proj.bias"); _dev(var_embed, F32, "var_embed")
+    _dev(ids, torch.int32, "ids")
+    cmat = torch.empty(5 * V, D, dtype=F32, device=w0.device)
+    _chk(lib().orbit2_tables_gather(_p(w0), C.c_int64(w_stride), _p(b0), C.c_int64(b_stride), _p(var_embed), _p(ids), _p(cmat),
+                                    V, D, _stream()), "orbit2_tables_gather")
+    return cmat
+
+
+def tables_scatter(dcmat, gw0, w_stride, gb0, b_stride, gvar_embed, ids, V, D):
+    """accumulates the rows' gradient into the parameters' gradient buffers (same pitches)"""
+    _dev(dcmat, F32, "dcmat"); _dev(gw0, F32, "dW"); _dev(gb0, F32, "db"); _dev(gvar_embed, F32, "dvar_embed")
+    _chk(lib().orbit2_tables_scatter(_p(dcmat), _p(gw0), C.c_int64(w_stride), _p(gb0), C.c_int64(b_stride), _p(gvar_embed),
+                                     _p(ids), V, D, _stream()), "orbit2_tables_scatter")
+
+
 def dropout_bwd(dy, M, N, drop_p, seed, rowscale=None, rows_per_scale=0, out=None):
     _dev(dy, BF, "dy")
     out = torch.empty_like(dy) if out is None else out

@@ -634,6 +634,59 @@ def sgemm(A, B, ta=False, tb=False):
 # embedding front-end: folded patch-embed + variable aggregation + proj + pos/res embedding + dropout
 #   (res_slimvit.py:250-284, attention.py:132-183, patch_embed.py:44-52)
 # ------------------------------------------------------------------------------------------------------
+class TokenTablesFn(torch.autograd.Function):
+    """cmat [5 V, D]: per used variable the four transposed patch-embed weight rows and bias + var_embed row (reference
+    res_slimvit.py:64-66, 182-201, 251-262) -- ONE launch forward; backward, the transpose accumulates straight into the engine's
+    flat fp32 gradient bucket (the per-variable parameters lie there at a uniform pitch) and tells the engine the parameters are
+    ready: no per-parameter autograd accumulation (2 V + 1 tiny launches per step in the small configurations).
+    Only for engine-managed parameters at a uniform pitch (`token_tables_layout`); the model keeps the ATen path otherwise."""
+    @staticmethod
+    def forward(ctx, layout, ids_t, V, D, var_embed, *te_params):
+        w0, ws, b0, bs = layout["w0"], layout["ws"], layout["b0"], layout["bs"]
+        ctx.layout, ctx.ids_t, ctx.V, ctx.D = layout, ids_t, V, D
+        ctx.params = (var_embed,) + tuple(te_params)
+        return _hip.tables_gather(w0.data, ws, b0.data, bs, var_embed.data.reshape(-1, D), ids_t, V, D)
+
+    @staticmethod
+    def backward(ctx, dcmat):
+        lay = ctx.layout
+        dcmat = dcmat.contiguous()
+        if dcmat.dtype != F32:
+            dcmat = dcmat.float()
+        var_embed = ctx.params[0]
+        _hip.tables_scatter(dcmat, lay["w0"].grad, lay["ws"], lay["b0"].grad, lay["bs"], var_embed.grad.view(-1, ctx.D), ctx.ids_t,
+                            ctx.V, ctx.D)
+        for p in ctx.params:                              # the engine counts these parameters as arrived (no AccumulateGrad runs)
+            p._o2_engine.grad_ready(p)
+        return (None,) * (5 + len(ctx.params) - 1)
+
+
+def token_tables_layout(token_embeds, var_embed):
+    """{w0, ws, b0, bs} if every per-variable patch-embed weight / bias (and their gradient views) lies at one uniform pitch in an
+    engine's flat buffers and everything requires a gradient; None otherwise (plain module, frozen parameters, other engines)"""
+    ws_ = [te.proj.weight for te in token_embeds]
+    bs_ = [te.proj.bias for te in token_embeds]
+    ps = ws_ + bs_ + [var_embed]
+    if any(getattr(p, "_o2_engine", None) is None or p.grad is None or not p.requires_grad or p.dtype != F32 or not p.is_cuda
+           for p in ps):
+        return None
+    if len({id(p._o2_engine) for p in ps}) != 1 or not var_embed.grad.is_contiguous():
+        return None
+    if len(ws_) == 1:
+        return {"w0": ws_[0], "ws": 0, "b0": bs_[0], "bs": 0}
+    pitch = lambda ts, attr: {(getattr(b, attr).data_ptr() - getattr(a, attr).data_ptr()) for a, b in zip(ts[:-1], ts[1:])}
+    out = {}
+    for key, ts in (("w", ws_), ("b", bs_)):
+        pd, pg = pitch(ts, "data"), pitch(ts, "grad")
+        if len(pd) != 1 or pd != pg:
+            return None
+        step = pd.pop()
+        if step <= 0 or step % 16:
+            return None
+        out[key + "0"], out[key + "s"] = ts[0], step // 4
+    return out
+
+
 class PosResFn(torch.autograd.Function):
     """the [L, D] fp32 table a step adds to its tokens: pos_embed re-gridded to the run's token grid (bicubic, only when the
     heights differ -- components/pos_embed.py:103-138) + the resolution embedding Linear(1, D)(res) (res_slimvit.py:277-281);

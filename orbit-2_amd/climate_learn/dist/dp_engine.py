@@ -213,6 +213,7 @@ class HipDataParallel(nn.Module):
                 self.flat32[o32:o32 + k].copy_(p.data.reshape(-1))
                 p.data = self.flat32[o32:o32 + k].view(p.shape)
                 p.grad = self.g32[og32:og32 + k].view(p.shape)
+                p._o2_engine = self                # (fused table kernels write such gradients themselves and call grad_ready)
                 if p.requires_grad:
                     bk.params.append(p)
                     self._bucket_of[id(p)] = bk
@@ -250,6 +251,7 @@ class HipDataParallel(nn.Module):
         self.comm_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
         self.comm_stats: Optional[CommStats] = None      # set to a CommStats() to account communication (bench, tests)
         self._launched: List[Bucket] = []
+        self._arrived = set()
         self.zero_grad()
 
     # ---- parameters <-> compute copies --------------------------------------------------------------
@@ -274,15 +276,20 @@ class HipDataParallel(nn.Module):
                 if hasattr(p, "_o2g"):
                     p._o2_fresh = True
         self._launched = []
+        self._arrived = set()
         self._replicas_synced = False
 
     def _hi_hook(self, p):
         self.grad_ready(p)
 
     def grad_ready(self, p):
+        """a parameter's gradient of this step is complete in its bucket.  Idempotent per step: a kernel that writes a gradient
+        itself announces it here, and autograd's post-accumulate hook may announce the same parameter again (it fires even when
+        the Function returned no gradient for it) -- counted twice, the bucket would be reduced before its last gradients exist"""
         bk = self._bucket_of.get(id(p))
-        if bk is None:
+        if bk is None or id(p) in self._arrived:
             return
+        self._arrived.add(id(p))
         bk.pending -= 1
         if bk.pending == 0:
             self._launch(bk)

@@ -165,14 +165,34 @@ class Res_Slim_ViT(nn.Module):
         ids_t = self._idx_cache.get(key)
         if ids_t is None:
             ids_t = self._idx_cache[key] = torch.tensor(list(ids), dtype=torch.long, device=wq.device)
-        w4 = torch.stack([te.weight.view(D, 4) for te in tes]).transpose(1, 2)    # [V, 4, D]
-        b1 = torch.stack([te.bias for te in tes]) + self.var_embed[0].index_select(0, ids_t)        # [V, D]
-        cmat = torch.cat([w4, b1.unsqueeze(1)], 1).reshape(len(ids) * 5, D)      # [(v,c), D]
+        lay = self._token_tables_layout() if torch.is_grad_enabled() else None
+        if lay is not None:
+            # engine-managed parameters at a uniform pitch: one launch forward, one backward that accumulates straight into
+            # the engine's gradient bucket (no stack / transpose / cat, no per-parameter autograd accumulation)
+            k32 = key + ("i32",)
+            ids32 = self._idx_cache.get(k32)
+            if ids32 is None:
+                ids32 = self._idx_cache[k32] = ids_t.to(torch.int32)
+            flat = [te.weight for te in tes] + [te.bias for te in tes]
+            cmat = _ops.TokenTablesFn.apply(lay, ids32, len(ids), D, self.var_embed, *flat)
+        else:
+            w4 = torch.stack([te.weight.view(D, 4) for te in tes]).transpose(1, 2)    # [V, 4, D]
+            b1 = torch.stack([te.bias for te in tes]) + self.var_embed[0].index_select(0, ids_t)        # [V, D]
+            cmat = torch.cat([w4, b1.unsqueeze(1)], 1).reshape(len(ids) * 5, D)      # [(v,c), D]
         if grp is not None:
             cmat = _tp.IdentityFwdAllReduceBwd.apply(cmat, grp)
         stab = _ops.sgemm(u, cmat, tb=True).view(H, len(ids), 5)
         gtab = _ops.sgemm(cmat, wkv[Dl:], tb=True).view(len(ids), 5, Dl)
         return stab, gtab
+
+    def _token_tables_layout(self):
+        """cached `_ops.token_tables_layout` (re-derived when the parameters move: another engine, a re-wrap)"""
+        w0 = self.token_embeds[0].proj.weight
+        sig = (id(getattr(w0, "_o2_engine", None)), w0.data_ptr(), w0.grad.data_ptr() if w0.grad is not None else 0)
+        hit = self._idx_cache.get("te_layout")
+        if hit is None or hit[0] != sig:
+            hit = self._idx_cache["te_layout"] = (sig, _ops.token_tables_layout(list(self.token_embeds), self.var_embed))
+        return hit[1]
 
     def _posres(self):
         """[L, D] fp32: pos_embed on the run's token grid (bicubic re-grid when the grid differs from the one the table

@@ -508,3 +508,67 @@ extern "C" int orbit2_varagg_bwd(const float* x, const float* gtab, const float*
   O2_CHECK_LAUNCH();
   return O2_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The per-variable rows the two tables are built from:  cmat[(v, c)][D],  c = 0..3: the patch-embed weight of variable ids[v]
+// seen as [D][4] (res_slimvit.py:64-66: PatchEmbed Conv2d(1, D, 2, 2).weight), transposed;  c = 4: its bias + var_embed[ids[v]]
+// (res_slimvit.py:182-201, 251-262).  The V_total per-variable parameters are separate tensors in the reference's state dict;
+// here they are addressed as base + index * stride (the engine lays them out at a uniform pitch in its flat buffers; the host
+// checks that before taking this path), so ONE launch replaces a stack + transpose + index_select + add + cat -- and its
+// transpose below replaces their autograd: per step 2 V + 1 gradient accumulations of a few KiB each.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void tables_gather_kernel(const float* __restrict__ wb, int64_t ws, const float* __restrict__ bb,
+                                                            int64_t bs, const float* __restrict__ ve, const int* __restrict__ ids,
+                                                            float* __restrict__ cmat, int D) {
+  const int v = blockIdx.x, id = ids[v];
+  const float* w = wb + (int64_t)id * ws;
+  const float* b = bb + (int64_t)id * bs;
+  const float* e = ve + (int64_t)id * D;
+  float* o = cmat + (size_t)v * 5 * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + (size_t)d * 4);
+    o[d] = w4[0]; o[D + d] = w4[1]; o[2 * D + d] = w4[2]; o[3 * D + d] = w4[3];
+    o[4 * D + d] = b[d] + e[d];
+  }
+}
+// gradients ACCUMULATE (the engine memsets its fp32 gradient bucket at the start of a step; distinct ids: no two workgroups touch
+// the same parameter)
+__global__ __launch_bounds__(256) void tables_scatter_kernel(const float* __restrict__ dc, float* __restrict__ dwb, int64_t ws,
+                                                             float* __restrict__ dbb, int64_t bs, float* __restrict__ dve,
+                                                             const int* __restrict__ ids, int D) {
+  const int v = blockIdx.x, id = ids[v];
+  float* dw = dwb + (int64_t)id * ws;
+  float* db = dbb + (int64_t)id * bs;
+  float* de = dve + (int64_t)id * D;
+  const float* g = dc + (size_t)v * 5 * D;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    f32x4 w4 = *reinterpret_cast<const f32x4*>(dw + (size_t)d * 4);
+    w4[0] += g[d]; w4[1] += g[D + d]; w4[2] += g[2 * D + d]; w4[3] += g[3 * D + d];
+    *reinterpret_cast<f32x4*>(dw + (size_t)d * 4) = w4;
+    const float gb = g[4 * D + d];
+    db[d] += gb;
+    de[d] += gb;
+  }
+}
+}  // namespace
+
+extern "C" int orbit2_tables_gather(const float* w_base, int64_t w_stride, const float* b_base, int64_t b_stride,
+                                    const float* var_embed, const int* ids, float* cmat, int V, int D, void* stream) {
+  if (!w_base || !b_base || !var_embed || !ids || !cmat || V <= 0 || D <= 0) return O2_ERR_ARG;
+  if (((uintptr_t)w_base & 15) || (w_stride & 3)) return O2_ERR_ARG;          // 16-byte rows of four patch weights
+  hipLaunchKernelGGL(tables_gather_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, w_base, w_stride, b_base, b_stride, var_embed,
+                     ids, cmat, D);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}
+
+extern "C" int orbit2_tables_scatter(const float* dcmat, float* dw_base, int64_t w_stride, float* db_base, int64_t b_stride,
+                                     float* dvar_embed, const int* ids, int V, int D, void* stream) {
+  if (!dcmat || !dw_base || !db_base || !dvar_embed || !ids || V <= 0 || D <= 0) return O2_ERR_ARG;
+  if (((uintptr_t)dw_base & 15) || (w_stride & 3)) return O2_ERR_ARG;
+  hipLaunchKernelGGL(tables_scatter_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, dcmat, dw_base, w_stride, db_base, b_stride,
+                     dvar_embed, ids, D);
+  O2_CHECK_LAUNCH();
+  return O2_OK;
+}

@@ -648,3 +648,44 @@ def test_lone_weight_gradient_split_over_tokens(monkeypatch):
     monkeypatch.setattr(_ops, "_DW_SPLIT", 0)
     gw0, _ = _ops._dw(dy, x, W, None, M, N, K)
     assert nerr(gw0, ref.cpu()) < 6e-3 and nerr(gw1, gw0.float().cpu()) < 8e-3
+
+
+def test_token_tables_fused_path_equals_the_aten_path(golden_dir):
+    """the per-variable patch-embed weights / biases and var_embed of an ENGINE-managed model go through `_ops.TokenTablesFn`
+    (one gather launch, one scatter that accumulates straight into the engine's flat fp32 gradient bucket, no per-parameter
+    autograd accumulation); a plain module takes the stack / transpose / cat path.  Same weights, same batch: the same loss and
+    bit-identical gradients for every one of those parameters; variables that are not in the batch's list keep a zero gradient;
+    a second step accumulates into a freshly zeroed bucket (no carry-over)."""
+    import climate_learn as cl
+    from climate_learn import _ops
+    from climate_learn.metrics import Bayesian_TV
+    from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
+    c, z, sd, plain = load(golden_dir, "v7c3_hd64")                      # default_vars: 8 variables, the batch uses 7 of them
+    c2, z2, sd2, managed = load(golden_dir, "v7c3_hd64")
+    eng = cl.HipDataParallel(managed, unit_types=(Block, nn.Sequential))
+    assert managed._token_tables_layout() is not None and plain._token_tables_layout() is None
+    batch = (torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), c["in_vars"], c["out_vars"])
+    lossf = Bayesian_TV(aggregate_only=True)
+    for step in range(2):
+        eng.zero_grad()
+        for p in plain.parameters():
+            p.grad = None
+        lm = training_step(batch, 0, eng, torch.device("cuda"), VW, lossf)
+        lm.backward()
+        eng.finish_grad_sync()
+        lp = training_step(batch, 0, plain, torch.device("cuda"), VW, lossf)
+        lp.backward()
+        assert float(lm) == float(lp)
+        names = [n for n, _ in plain.named_parameters() if n.startswith("token_embeds.") or n == "var_embed"]
+        gm, gp = dict(managed.named_parameters()), dict(plain.named_parameters())
+        touched = 0
+        for n in names:
+            a = gm[n].grad
+            b = gp[n].grad
+            if b is None:                                                # a variable the batch does not carry
+                assert float(a.abs().max()) == 0.0, n
+                continue
+            touched += 1
+            assert torch.equal(a, b), (n, step, float((a - b).abs().max()))
+        assert touched == 2 * len(c["in_vars"]) + 1
