@@ -22,8 +22,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
 // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  (The scalar form -- two conversions, a mask
+// and a shift-or -- cost four instructions per pair in every epilogue and elementwise kernel that stores bf16; same rounding,
+// same bits.)
+typedef __attribute__((ext_vector_type(2))) float o2_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 o2_bf16x2;
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const o2_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, o2_bf16x2));
 }
 
 // 16-byte LDS-DMA: every lane supplies its own global source; the LDS destination is
