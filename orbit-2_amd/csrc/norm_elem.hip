@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // thread owning the chunks tid, tid + TPB, ..: a quarter of the accumulators per thread, one LDS exchange + barrier per row for the two
 // row statistics (double-buffered slots), the next row's loads issued before that barrier, and the block's partial
 // dgamma / dbeta row written straight from registers (the waves own disjoint columns).
-template <int NCW, int TPB = 256, int RPB = 4 * LN_RPW>
+// EXACT: D == 8 NCW TPB -- no chunk is ever out of range, so no lane is ever masked off: without the tests the loop loses its
+// exec-mask bookkeeping (19 s_and_saveexec + 20 s_or + the copies that merge the masked paths)
+template <int NCW, int TPB = 256, int RPB = 4 * LN_RPW, bool EXACT = false>
 __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ gamma,
                                                           const float* __restrict__ mean,
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
 #pragma unroll
   for (int c = 0; c < NCW; ++c) {
     const int ch = tid + c * TPB;
-    gp[c] = ch < nch ? *reinterpret_cast<const u32x4*>(gamma + ch * 8) : (u32x4){0u, 0u, 0u, 0u};
+    gp[c] = (EXACT || ch < nch) ? *reinterpret_cast<const u32x4*>(gamma + ch * 8) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
   }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < NCW; ++c) {
       const int ch = tid + c * TPB;
-      if (ch < nch) {
+      if (EXACT || ch < nch) {
         xo[c] = *reinterpret_cast<const u32x4*>(x + (size_t)row * D + ch * 8);
         dyo[c] = *reinterpret_cast<const u32x4*>(dy + (size_t)row * D + ch * 8);
         if (dres) ro[c] = *reinterpret_cast<const u32x4*>(dres + (size_t)row * D + ch * 8);
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCW; ++c) {
-      if (tid + c * TPB < nch) {
+      if (EXACT || tid + c * TPB < nch) {
         float xv[8], dv[8], gv[8];
         unpack8(xp[c], xv); unpack8(dp[c], dv); unpack8(gp[c], gv);
 #pragma unroll
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < NCW; ++c) {
       const int ch = tid + c * TPB;
-      if (ch < nch) {
+      if (EXACT || ch < nch) {
         float xv[8], dv[8], gv[8], o[8];
         unpack8(xp[c], xv); unpack8(dp[c], dv); unpack8(gp[c], gv);
 #pragma unroll
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
 #pragma unroll
   for (int c = 0; c < NCW; ++c) {
     const int ch = tid + c * TPB;
-    if (ch < nch) {
+    if (EXACT || ch < nch) {
       *reinterpret_cast<f32x4*>(pout + ch * 8) = (f32x4){dg[c][0], dg[c][1], dg[c][2], dg[c][3]};
       *reinterpret_cast<f32x4*>(pout + ch * 8 + 4) = (f32x4){dg[c][4], dg[c][5], dg[c][6], dg[c][7]};
       *reinterpret_cast<f32x4*>(pout + D + ch * 8) = (f32x4){db[c][0], db[c][1], db[c][2], db[c][3]};
@@ -726,16 +728,21 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
   // small grids: 4096 rows would otherwise occupy 64 CUs).  The workspace holds 4 partial rows per 64 input rows.
   const bool few = rows < 32768;
   const int npart_used = few ? ln_bwd_nparts_few(rows) : nparts / 4;
-#define WIDE(NCW, TPB)                                                                                              \
+#define WIDE_(NCW, TPB, EX)                                                                                         \
   do {                                                                                                              \
     if (few)                                                                                                        \
-      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, LN_FEW_RPB>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,   \
+      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, LN_FEW_RPB, EX>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy, \
                          (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws,  \
                          rows, D);                                                                                  \
     else                                                                                                            \
-      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, 64>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,   \
+      hipLaunchKernelGGL((ln_bwd_wide_kernel<NCW, TPB, 64, EX>), dim3(npart_used), dim3(TPB), 0, s, (const bf16_t*)dy,  \
                          (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, ws,  \
                          rows, D);                                                                                  \
+  } while (0)
+#define WIDE(NCW, TPB)                                                                                              \
+  do {                                                                                                              \
+    if (D == 8 * (NCW) * (TPB)) WIDE_(NCW, TPB, true);                                                              \
+    else WIDE_(NCW, TPB, false);                                                                                    \
   } while (0)
   if (D == 3072) WIDE(3, 128);          // 363 vs 414 us (per-wave form) at 65536 rows
   else if (D == 1024) WIDE(1, 128);
@@ -756,6 +763,7 @@ extern "C" int orbit2_layernorm_bwd(const void* dy, const void* x, const void* g
 #undef CALL
   }
 #undef WIDE
+#undef WIDE_
   O2_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, ws, npart_used, D, dgamma, dbeta,
                      grads_fp32, beta_acc);
