@@ -14,6 +14,7 @@ import os
 import sys
 import time
 
+T_PROCESS_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "orbit-2_amd")):
     if p not in sys.path:
@@ -57,6 +58,9 @@ def parse():
                     help="per-GPU batch: 16 (1 / 2 / 4 / 8 / 16 / 32 all fit one GPU; 8 is 1 % slower, 32 = the reference "
                          "YAML's batch_size gives the same rate at twice the step time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the child runs of the other BASELINE configs (interm_117m 32x64 batch 8, the Daymet-like interm_1b "
+                         "step, interm_10b batch 2) that the default single-GPU run attaches as `other_configs`")
     ap.add_argument("--no-comm-stats", action="store_true",
                     help="do not attach CommStats (timing events + collective waits on the communication stream) to the engine: "
                          "A/B of what the accounting itself costs (tools/forced_collectives_ab.sh)")
@@ -198,7 +202,12 @@ def cpu_baseline(model_name, V, C):
     t2 = _oracle_steps("interm_117m", ERA5_VARS, OUT_VARS, 8, (32, 64), "bayesian_tv", 2, 5, "config2 interm_117m")
     m1, m2 = statistics.median(t1), statistics.median(t2)
     out = {"value": 8.0 / m2, "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": "oracle (plain PyTorch fp32 restatement of the reference) fwd+loss+bwd+AdamW of BASELINE configs[1]: "
+           # `value` is NOT the GPU line's workload (interm_1b at 128x256 cannot finish on host cores in the bench's
+           # budget): a reader must not divide one by the other; the same-model estimate is `interm_1b_tile_estimate`
+           "same_workload": False,
+           "sample": "NOT the workload of the GPU line (interm_1b, 128x256): that one is only ESTIMATED, see "
+                     "`interm_1b_tile_estimate` (one 16x32 tile extrapolated by the FLOP ratio).  `value` here = "
+                     "oracle (plain PyTorch fp32 restatement of the reference) fwd+loss+bwd+AdamW of BASELINE configs[1]: "
                      "interm_117m, x[8,23,32,64] -> [8,3,128,256], bayesian_tv; 2 warm-up steps, median of 5 timed steps "
                      "(%.2f s/step); measured, not extrapolated.  The GPU line above is interm_1b at 128x256, which no CPU "
                      "run of this length can reach: see `interm_1b_tile_estimate`" % m2,
@@ -235,6 +244,53 @@ def forward_flops(L, V, D, depth, dd, C, h, w, heads, p=2, s=4, cr=4, r=4, folde
     head = dd * 2 * L * D * D + 2 * L * D * C * (p * s) ** 2
     convs = 2 * h * w * (C + 4) * (cr * s * s) * 9 + 2 * (16 * h * w) * cr * C * 9 + 2 * (16 * h * w) * C * C * 9
     return va + blk + head + convs
+
+
+OTHER_CONFIGS = (
+    # (key, BASELINE.json config it stands for, bench arguments, seconds allowed)
+    ("interm_117m_32x64_b8", "configs[1]: interm_117m bf16, ERA5 5.625 -> 1.40625 deg synthetic grids, 1 x MI355X",
+     ["--model", "interm_117m", "--grid", "32x64", "--batch", "8", "--steps", "40", "--warmup", "10"], 150),
+    ("interm_1b_daymet_96x192_b4", "configs[4]: interm_1b, Daymet-like 7 -> 3 variables, hybrid perceptual + lat-weighted MSE loss",
+     ["--daymet", "--grid", "96x192", "--batch", "4", "--steps", "6", "--warmup", "2"], 150),
+    ("interm_10b_128x256_b2", "configs[3]: interm_10b bf16, ERA5 1.40625 -> 0.25 deg (128x256), per-GPU batch 2",
+     ["--model", "interm_10b", "--batch", "2", "--steps", "3", "--warmup", "1"], 240),
+)
+
+
+def other_configs(t_start, budget_s=420.0):
+    """The other BASELINE configs on the driver's clock: each one is this same script run as a CHILD process
+    (a fresh interpreter started with subprocess after this process has released its device memory; never an exec of the
+    process that holds the GPU), its JSON line reduced to {value, ms_per_step, roofline.frac, config}.  A config is skipped,
+    and says so, when the time already spent plus its allowance would pass `budget_s` (the default run must stay within minutes)."""
+    import subprocess
+    out = {}
+    for key, what, args, allow in OTHER_CONFIGS:
+        spent = time.perf_counter() - t_start
+        if spent + allow > budget_s:
+            out[key] = {"skipped": "time budget: %.0f s spent, %d s allowance, %.0f s budget" % (spent, allow, budget_s), "stands_for": what}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__)] + args + ["--no-cpu-baseline", "--no-other-configs"]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=allow)
+            lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[key] = {"error": "exit code %d" % r.returncode, "stderr_tail": r.stderr.decode(errors="replace")[-600:], "stands_for": what}
+                continue
+            d = json.loads(lines[-1])
+            ra = d.get("roofline_attention") or {}
+            out[key] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                        "roofline": {"frac": (d.get("roofline") or {}).get("frac"), "bound": "mfma",
+                                     "note": "executed FLOPs of the step / 2.5 PFLOP/s, as the headline line"},
+                        "roofline_gemm_frac": (d.get("roofline_gemm") or {}).get("frac"),
+                        "roofline_attention_frac": ra.get("frac"),
+                        "config": d["config"], "dtype": d["dtype"], "stands_for": what, "wall_s": time.perf_counter() - t0,
+                        "command": "python bench.py " + " ".join(args)}
+        except subprocess.TimeoutExpired:
+            out[key] = {"error": "still running after %d s (killed)" % allow, "stands_for": what}
+    return out
 
 
 def self_launch(a):
@@ -579,9 +635,17 @@ def main():
                                if cst["comm_ms_per_step"] > 0 else None)
             out["comm_ms_per_step"] = cst["comm_ms_per_step"]
             out["exposed_comm_ms"] = cst["exposed_comm_ms_per_step"]
-        if world == 1 and (a.eager_baseline or not a.no_cpu_baseline):
+        default_run = (a.model == "interm_1b" and a.grid == "128x256" and not a.daymet and tp == 1 and not a.fsdp and not a.recompute)
+        if world == 1 and (a.eager_baseline or not a.no_cpu_baseline or (default_run and not a.no_other_configs)):
+            # release the headline run's device memory: the closures hold the engine, the optimizer and the batch too
+            import gc as _gc
+            step = fence = last = gstep = loss_fn = scaler = x = y = None          # noqa: F841
             del eng, opt, model, batch
+            _gc.collect()
             torch.cuda.empty_cache()
+            print("[bench] released; device memory still allocated: %.1f GB" % (torch.cuda.memory_allocated() / 1e9), file=sys.stderr)
+        if world == 1 and default_run and not a.no_other_configs:
+            out["other_configs"] = other_configs(T_PROCESS_START)
         if world == 1 and a.eager_baseline and not a.daymet:
             out["gpu_eager_baseline"] = gpu_eager_baseline(a.model, V, C, a.eager_baseline, dev)
             torch.cuda.empty_cache()

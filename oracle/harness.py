@@ -127,6 +127,47 @@ def grad_tolerance(spread, name=None, stress=False):
     return tol
 
 
+_ADMITTED = os.environ.get("ORBIT2_TOL_ADMITTED",
+                           os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tolerance_admitted.txt"))
+
+
+def admitted(case, name, err, spread, tol, kind="max"):
+    """every tensor that passes ABOVE the 2e-2 floor (because its measured bf16 spread loosens its bound) is
+    written, with its error, spread and bound, to gpurun_out/tolerance_admitted.txt -- one suite run's file is kept as
+    profiles/r06_tolerance_admitted.txt, so loosened tensors are visible in review.  Never raises (a read-only tree logs nothing)."""
+    if float(err) <= TOL_FLOOR:
+        return
+    try:
+        os.makedirs(os.path.dirname(_ADMITTED), exist_ok=True)
+        with open(_ADMITTED, "a") as f:
+            f.write("%-28s %-4s %-44s err %.4f  bf16 spread %.4f  bound %.4f\n" % (case, kind, name, float(err), float(spread), float(tol)))
+    except OSError:
+        pass
+
+
+def whole_gradient_rel_l2(pairs):
+    """relative L2 over ALL parameters together: sqrt(sum |g_hip - g_ref|^2 / sum |g_ref|^2) of (hip, reference) pairs -- the
+    bound that a regression confined to one loosely bounded tensor (pos_embed, token_embeds.*, norm1.*) cannot hide under"""
+    num = den = 0.0
+    for a, b in pairs:
+        a = torch.as_tensor(a).detach().float().cpu().double()
+        b = torch.as_tensor(b).detach().float().cpu().double()
+        num += float((a - b).pow(2).sum())
+        den += float(b.pow(2).sum())
+    return (num / max(den, 1e-300)) ** 0.5
+
+
+def whole_gradient_spread(l2_spreads, ref_grads):
+    """what the REFERENCE's own bf16 run moves the whole gradient by, from the committed per-tensor relative-L2 spreads and
+    the fp32 gradients: sqrt(sum (l2_t |g_t|)^2 / sum |g_t|^2) (exact when the per-tensor spreads are, as they are, rel. L2)"""
+    num = den = 0.0
+    for n, g in ref_grads.items():
+        nn_ = float(torch.as_tensor(g).double().pow(2).sum())
+        num += (float(l2_spreads[n]) ** 2) * nn_
+        den += nn_
+    return (num / max(den, 1e-300)) ** 0.5
+
+
 def oracle_bf16_spread(O, sd, cfg, x, y, in_vars, out_vars, loss="bayesian_tv", vw=None, fp32_grads=None, **kw):
     """the yardstick where no reference fixture exists for the configuration: the oracle (pinned to the reference by
     tests/test_oracle_golden.py) run once more with weights, inputs and arithmetic in plain bf16; returns
@@ -183,3 +224,10 @@ def smoke_step():
           "(reference bf16 spread %.2e, tol %.2e)" % (float(loss), float(ref), e_loss, e_g, sp["head.0.weight"], t_g, e_q,
                                                       sp["blocks.0.attn.qkv.weight"], t_q), flush=True)
     assert e_loss < 2e-2 and e_g <= t_g and e_q <= t_q, "HIP step disagrees with the CPU oracle"
+    # the whole gradient (every parameter together): relative L2 <= 2e-2, or 1.5 x what bf16 moves it in the reference's model
+    names = [n for n, p in model.named_parameters() if p.grad is not None and sdo[n].grad is not None]
+    e_all = whole_gradient_rel_l2((dict(model.named_parameters())[n].grad, sdo[n].grad) for n in names)
+    sp_all = whole_gradient_spread({n: sp["l2." + n] for n in names}, {n: sdo[n].grad for n in names})
+    t_all = max(TOL_FLOOR, TOL_FACTOR * sp_all)
+    print("[smoke] whole gradient (%d tensors): rel. L2 %.2e (reference bf16 spread %.2e, bound %.2e)" % (len(names), e_all, sp_all, t_all), flush=True)
+    assert e_all <= t_all, "whole-gradient relative L2 %.3e exceeds %.3e" % (e_all, t_all)

@@ -101,7 +101,7 @@ class ReplicaGuard:
     near-zero gradient becomes +-lr under AdamW and the replicas drift apart silently.  Policy (ORBIT2_TP_REPLICA_SYNC):
       auto (default)  broadcast the replica gradient ranges from the group's first rank after the data-parallel reduction
                       whenever (a) or (b) is not guaranteed; otherwise no exchange, but every `check_every`-th step (and the
-                      first) an exact checksum of the ranges is compared across the group and a mismatch raises;
+                      first) a pair of checksums of the ranges (plain and position-weighted) is compared across the group and a mismatch raises;
       broadcast       always broadcast;   check  never broadcast, always compare;   off  neither."""
 
     def __init__(self, group, data_world: int, check_every: int = 100):
@@ -130,17 +130,25 @@ class ReplicaGuard:
             self.broadcasts += 1
             return
         if self.mode == "check" or self.steps == 1 or self.steps % self.check_every == 0:
-            # exact and order-free: the int64 sum of the raw words of every range (any flipped bit changes it), and the
-            # word count; equal on all ranks <=> max == min
+            # two checksums per range over its raw words w[i], in wrapping int64: sum w[i] and sum (2 i + 1) w[i].  The plain sum
+            # alone passes two words that differ by opposite amounts (+1 ulp here, -1 ulp there) and any permutation; the
+            # position-weighted one does not (odd weights: a single differing word always changes it; two that cancel in the
+            # plain sum change it by delta x 2 (j - i) != 0).  Equal on all ranks <=> max == min.  (advisor, round 5)
             sums = []
             for v in views:
-                raw = v.view(torch.int16) if v.element_size() == 2 else v.view(torch.int32)
-                sums.append(raw.sum(dtype=torch.int64))
+                raw = (v.view(torch.int16) if v.element_size() == 2 else v.view(torch.int32)).reshape(-1)
+                s0 = torch.zeros((), dtype=torch.int64, device=raw.device)
+                s1 = torch.zeros((), dtype=torch.int64, device=raw.device)
+                for a in range(0, raw.numel(), 1 << 24):                       # (bounded temporaries: 16 M words at a time)
+                    w = raw[a:a + (1 << 24)].to(torch.int64)
+                    s0 += w.sum()
+                    s1 += (w * (2 * torch.arange(a, a + w.numel(), dtype=torch.int64, device=raw.device) + 1)).sum()
+                sums += [s0, s1]
             mine = torch.stack(sums)
             hi, lo = all_reduce_max(mine.clone(), self.group), -all_reduce_max(-mine.clone(), self.group)
             self.checks += 1
             if not torch.equal(hi, lo):
-                bad = [i for i in range(len(views)) if int(hi[i]) != int(lo[i])]
+                bad = [i for i in range(len(views)) if int(hi[2 * i]) != int(lo[2 * i]) or int(hi[2 * i + 1]) != int(lo[2 * i + 1])]
                 raise RuntimeError("tensor-parallel replicas disagree: the gradient ranges %s of the parameters replicated over "
                                    "the group differ between its ranks at step %d (a non-reproducible kernel or reduction "
                                    "order on their path); run with ORBIT2_TP_REPLICA_SYNC=broadcast" % (bad, self.steps))

@@ -328,6 +328,26 @@ __device__ __forceinline__ int xcd_tile_id() {
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
 }
 
+// Round-major form for the kernels that hold ONE workgroup per CU (the 4-wave 256 x 256 kernel): the 256 workgroups that run at
+// the same time (block b lands on XCD b & 7, in dispatch order) take 256 CONSECUTIVE tile ids -- a compact block of the output --
+// and each XCD 32 consecutive ids of those (its L2 cohort, 4 x 8 tiles).  With xcd_tile_id the eight XCDs work on eight distant
+// id ranges: a panel strip that two of them need is needed milliseconds apart and comes from HBM twice; here the 8 cohorts of a
+// round sweep K side by side and the second reader of a strip finds it in the Infinity Cache.  What that buys: the clock
+// (profiles/r06_dw_traffic_clock.txt, r06_dw_traffic_instep.txt: the weight-gradient launch with its panels served from the
+// Infinity Cache runs 13 % faster at the same MFMA-busy share).  Bijective for any grid size.
+__device__ __forceinline__ int xcd_round_tile_id() {
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int base = b & ~255;
+  const int cnt = (nwg - base) < 256 ? (nwg - base) : 256;          // workgroups of this round
+  const int x = b & 7, s = (b & 255) >> 3;
+  const int q8 = cnt >> 3, r8 = cnt & 7;
+  return base + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + s;
+}
+#ifndef O2_W4_WALK
+#define O2_W4_WALK 1        // 1: round-major ids for the 4-wave kernels; 0: the contiguous-range-per-XCD ids of rounds 2-5 (A/B builds)
+#endif
+__device__ __forceinline__ int w4_tile_id() { return O2_W4_WALK ? xcd_round_tile_id() : xcd_tile_id(); }
+
 // one 128x128 output tile (tile `id` of the problem; tiles are walked in groups of 8 tile-rows so neighbours
 // share panels)
 // MT = rows of the tile: 128, or 64 (A K-contiguous only) -- half the rows per workgroup, twice the workgroups: problems whose
@@ -844,13 +864,26 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  constexpr int GROUP = 4;
-  const int per_group = GROUP * tiles_n;
+#ifndef O2_W4_GROUP
+#define O2_W4_GROUP 4
+#endif
+  constexpr int GROUP = O2_W4_GROUP;
+  // ids walk groups of GROUP tile-rows, m fastest: 32 consecutive ids = 4 x 8 tiles (12 panel strips per K-tile for 32 tiles).  A
+  // problem that is wider than tall (tiles_n > tiles_m: the fc2 weight gradient, 12 x 48) is walked the other way round, groups of
+  // GROUP tile-columns with n fastest: the 256 consecutive ids of a round (xcd_round_tile_id) then cover ~21 x 12 tiles = 33 strips
+  // instead of 5 x 48 = 53
+#ifndef O2_W4_TWALK
+#define O2_W4_TWALK 1
+#endif
+  const bool tw = O2_W4_TWALK && tiles_n > tiles_m;
+  const int t_major = tw ? tiles_n : tiles_m, t_minor = tw ? tiles_m : tiles_n;
+  const int per_group = GROUP * t_minor;
   const int grp = id / per_group;
-  const int first_m = grp * GROUP;
-  const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (id % per_group) % gsz;
-  const int tn = (id % per_group) / gsz;
+  const int first_g = grp * GROUP;
+  const int gsz = (t_major - first_g) < GROUP ? (t_major - first_g) : GROUP;
+  const int t_a = first_g + (id % per_group) % gsz;
+  const int t_b = (id % per_group) / gsz;
+  const int tm = tw ? t_b : t_a, tn = tw ? t_a : t_b;
   const int m0 = tm * BM2, n0 = tn * BN2;
 
 #ifdef O2_W4_STAMP
@@ -1043,7 +1076,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w_kernel(const bf16_t* __restri
                                                           int M, int N, int K, int lda, int ldb, int tiles_m,
                                                           int tiles_n, Epi epi) {
   __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
-  gemm256w_tile<FORM, STAMP, EK>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, xcd_tile_id(), smem);
+  gemm256w_tile<FORM, STAMP, EK>(A, B, M, N, K, lda, ldb, tiles_m, tiles_n, epi, w4_tile_id(), smem);
 }
 
 // the epilogue kind of epi8_finish a whole-tile bf16 problem qualifies for (0: the runtime form)
@@ -1062,7 +1095,7 @@ static int w4_epi_kind(const Epi& e) {
 template <int FORM>
 __global__ __launch_bounds__(256, 1) void gemm256w_grouped_kernel(GArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
-  const int id = xcd_tile_id();
+  const int id = w4_tile_id();
   int pi = 0;
   while (pi + 1 < g.n && id >= g.p[pi].tile_end) ++pi;
   const int first = pi ? g.p[pi - 1].tile_end : 0;

@@ -66,6 +66,16 @@ def run_child(test_file, func, *args, timeout=900, env=None):
     return r
 
 
+def _how(code):
+    """exit status in words: 'exit code 3', 'killed by SIGSEGV'"""
+    if isinstance(code, int) and code < 0:
+        try:
+            return "killed by %s" % signal.Signals(-code).name
+        except ValueError:
+            return "killed by signal %d" % -code
+    return "exit code %s" % code if isinstance(code, int) else str(code)
+
+
 def spawn_ranks(worker, world, *args, timeout=900):
     """`worker(rank, world, port, *args, q)` in `world` spawned processes; every rank reports (rank, "ok" | text, ...) on q.  A
     rank that dies without reporting (signal, abort in a non-Python thread) is named with its exit status at once instead of
@@ -96,22 +106,23 @@ def spawn_ranks(worker, world, *args, timeout=900):
                 break
         if time.time() - t0 > timeout:
             dead = (-1, "no report after %d s" % timeout)
-    for p in procs:
+    hung = []
+    for r, p in enumerate(procs):
         p.join(60 if dead is None else 5)
         if p.is_alive():
+            hung.append(r)
             p.terminate()
             p.join(10)
     if dead is not None:
         r, code = dead
-        how = code
-        if isinstance(code, int) and code < 0:
-            try:
-                how = "killed by %s" % signal.Signals(-code).name
-            except ValueError:
-                how = "killed by signal %d" % -code
-        raise AssertionError("rank %s ended without reporting: %s; reports so far: %r" % (r, how, [x[:2] for x in res]))
+        raise AssertionError("rank %s ended without reporting: %s; reports so far: %r" % (r, _how(code), [x[:2] for x in res]))
     for r in res:
         assert r[1] == "ok", "rank %s:\n%s" % (r[0], "\n".join(str(x) for x in r[1:]))
+    # a rank that reported "ok" and THEN died (destroy_process_group in its `finally`, interpreter or RCCL teardown) is the crash
+    # class this runner exists to attribute: every exit status is examined after the joins (advisor, round 5)
+    late = [(r, p.exitcode) for r, p in enumerate(procs) if r not in hung and p.exitcode != 0]
+    assert not hung, "rank(s) %s reported ok but were still running 60 s later (terminated)" % hung
+    assert not late, "; ".join("rank %d reported ok but exited with %s" % (r, _how(c)) for r, c in late)
     return sorted(res, key=lambda r: r[0])
 
 

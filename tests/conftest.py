@@ -31,15 +31,19 @@ def _open_side_files():
         _progress = open(os.path.join(_PROGRESS_DIR, "pytest_nodeids.log"), "a", buffering=1)
         _fault = open(os.path.join(_PROGRESS_DIR, "pytest_fault.log"), "a", buffering=1)
         faulthandler.enable(file=_fault, all_threads=True)
-    except OSError:                                  # read-only tree: stdout still names the test
-        _progress = False
+    except OSError:                                  # read-only tree: stdout still names the test, and the fault dump goes to
+        _progress = False                            # stderr (pytest's own faulthandler plugin is off: without this a crash of the
+        faulthandler.enable(all_threads=True)        # parent would leave no Python traceback anywhere)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _open_side_files()
     if _progress:
-        _progress.write("==== session %s pid %d args %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), os.getpid(), " ".join(sys.argv[1:])))
+        head = "==== session %s pid %d args %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), os.getpid(), " ".join(sys.argv[1:]))
+        _progress.write(head)
+        if _fault:
+            _fault.write(head)                       # (append mode: a dump is then attributable to its session)
 
 
 def pytest_runtest_logstart(nodeid, location):

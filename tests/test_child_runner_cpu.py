@@ -57,6 +57,11 @@ def _rank_worker(rank, world, port, mode, q):
         os.kill(os.getpid(), signal.SIGKILL)      # dies without reporting
     elif mode == "one_fails" and rank == 0:
         q.put((rank, "fail", "Traceback: boom"))
+    elif mode == "dies_in_teardown":
+        q.put((rank, "ok"))
+        if rank == 1:                             # reports first, THEN aborts (a fault in destroy_process_group / interpreter exit)
+            time.sleep(0.5)                       # (lets the queue's feeder thread hand the report over)
+            os.kill(os.getpid(), signal.SIGABRT)
     else:
         time.sleep(2.0)
         q.put((rank, "ok"))
@@ -79,3 +84,10 @@ def test_spawn_ranks_relays_a_reported_failure():
     with pytest.raises(AssertionError) as e:
         spawn_ranks(_rank_worker, 2, "one_fails", timeout=60)
     assert "rank 0" in str(e.value) and "boom" in str(e.value)
+
+
+def test_spawn_ranks_names_a_rank_that_died_after_reporting_ok():
+    """advisor, round 5: a rank that reports ok and then dies in its teardown used to be joined without a look at its exit status"""
+    with pytest.raises(AssertionError) as e:
+        spawn_ranks(_rank_worker, 2, "dies_in_teardown", timeout=60)
+    assert "rank 1 reported ok but exited with killed by SIGABRT" in str(e.value)

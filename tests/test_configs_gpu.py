@@ -74,6 +74,10 @@ def test_interm_117m_whole_model_forward_backward_vs_oracle():
     bad = {k: (e, sp[k], l2[k], sp["l2." + k]) for k, e in worst.items()
            if e > grad_tolerance(sp[k], k) or l2[k] > grad_tolerance(sp["l2." + k])}
     assert len(worst) > 120 and not bad, bad
+    from oracle.harness import admitted
+    for k, e in worst.items():                                            # what passed above the 2e-2 floor goes on record
+        admitted("interm_117m_vs_oracle", k, e, sp[k], grad_tolerance(sp[k]))
+        admitted("interm_117m_vs_oracle", k, l2[k], sp["l2." + k], grad_tolerance(sp["l2." + k]), kind="l2")
     # beside the per-tensor bounds, the whole gradient: relative L2 over all parameters together
     num = sum(float((p.grad.detach().float().cpu().double() - sdo[n].grad.double()).pow(2).sum()) for n, p in model.named_parameters()
               if sdo[n].grad is not None)

@@ -130,6 +130,21 @@ def _worker(rank, world, port, q):
             raise AssertionError("a replica mismatch went unnoticed")
         except RuntimeError as e:
             assert "replicas disagree" in str(e) and "[1]" in str(e)
+        # two words that differ by OPPOSITE raw amounts (and a permutation) cancel in a plain sum of the words: the
+        # position-weighted checksum must still see them (advisor, round 5)
+        for kind in ("opposite", "swap"):
+            canc = [v.clone() for v in same]
+            if rank == 1:
+                w = canc[0].view(torch.int16)
+                if kind == "opposite":
+                    w[3] += 1; w[7] -= 1
+                else:
+                    w[[3, 7]] = w[[7, 3]]
+            try:
+                tp.ReplicaGuard(tpg, data_world=1).after_reduction(canc)
+                raise AssertionError("a replica mismatch that cancels in the plain sum went unnoticed (%s)" % kind)
+            except RuntimeError as e:
+                assert "replicas disagree" in str(e) and "[0]" in str(e)
         g3 = tp.ReplicaGuard(tpg, data_world=2)                           # data parallelism beside the group: exchange
         assert g3.needs_broadcast()
         g3.after_reduction(bad)

@@ -65,9 +65,28 @@ def tile_loads(a_kc, b_kc):
     return out
 
 
-def k_advance(first):
+def k_advance(first, kwrap=0):
     """the K advance moves the 48-bit BASE of the two buffer descriptors (SALU): the 32-bit per-lane offset of a K-strided
-    operand would pass 2^31 -- the descriptors' range -- at K x row pitch x 2 B > 2 GiB (131072 tokens x 9216 columns)"""
+    operand would pass 2^31 -- the descriptors' range -- at K x row pitch x 2 B > 2 GiB (131072 tokens x 9216 columns).
+    kwrap = n (a power of two; TIMING-ONLY ablation, wrong products): the loop walks the first n K-tiles of its panels over and
+    over (every n-th advance steps back by n - 1), so the same MFMAs / LDS traffic / LDS-DMA pieces run with the panel reads
+    served from L2 -- what the traffic beyond L2 costs (profiles/r06_dw_traffic_clock.txt)."""
+    if kwrap:
+        n = kwrap
+        return first + [
+            "s_and_b32 s%d, s%d, %d" % (S_X, S_X, n - 1),
+            "s_mul_i32 s96, %%[ka], %d" % -(n - 1),
+            "s_mul_i32 s97, %%[kb], %d" % -(n - 1),
+            "s_cmp_eq_u32 s%d, 0" % S_X,
+            "s_cselect_b32 s%d, s96, %%[ka]" % S_X,
+            "s_cselect_b32 s%d, s97, %%[kb]" % S_X2,
+            "s_ashr_i32 s96, s%d, 31" % S_X,
+            "s_ashr_i32 s97, s%d, 31" % S_X2,
+            "s_add_u32 s%d, s%d, s%d" % (S_DA, S_DA, S_X),
+            "s_addc_u32 s%d, s%d, s96" % (S_DA + 1, S_DA + 1),
+            "s_add_u32 s%d, s%d, s%d" % (S_DB, S_DB, S_X2),
+            "s_addc_u32 s%d, s%d, s97" % (S_DB + 1, S_DB + 1),
+        ]
     return first + [
         "s_cmp_lt_u32 s%d, %%[nk]" % S_X,
         "s_cselect_b32 s%d, %%[kb], 0" % S_X2,
@@ -110,7 +129,7 @@ def gen(a_kc, b_kc, cfg):
             e(setm0)
             e("s_nop 0")
             e(ld)
-        for x in k_advance(["s_mov_b32 s%d, %d" % (S_X, tile + 1)]):
+        for x in k_advance(["s_mov_b32 s%d, %d" % (S_X, tile + 1)], cfg.get("kwrap", 0)):
             e(x)
         for x in flip_write_bases():
             e(x)
@@ -160,12 +179,17 @@ def gen(a_kc, b_kc, cfg):
         gaps[g_].append(ld)
     b2 = cfg["bar2"]
     gaps[b2] += ["s_waitcnt vmcnt(%d)" % sum(1 for x in lg if x < b2), "s_barrier"]
-    ka_ = k_advance(["s_add_u32 s%d, s%d, 3" % (S_X, S_T)])
+    ka_ = k_advance(["s_add_u32 s%d, s%d, 3" % (S_X, S_T)], cfg.get("kwrap", 0))
     ga = max(lg) + 1
     assert ga + 3 <= 125, "pieces run too late"
-    gaps[ga] += ka_[:4]                          # s_cmp + s_cselects stay together (SCC)
-    gaps[ga + 1] += ka_[4:6]                     # s_add / s_addc pairs stay together (carry)
-    gaps[ga + 2] += ka_[6:8]
+    if cfg.get("kwrap"):
+        gaps[ga] += ka_[:7]                      # (ablation) s_cmp + s_cselects stay together (SCC)
+        gaps[ga + 1] += ka_[7:11]                # s_add / s_addc pairs stay together (carry)
+        gaps[ga + 2] += ka_[11:13]
+    else:
+        gaps[ga] += ka_[:4]                      # s_cmp + s_cselects stay together (SCC)
+        gaps[ga + 1] += ka_[4:6]                 # s_add / s_addc pairs stay together (carry)
+        gaps[ga + 2] += ka_[6:8]
     gaps[ga + 3] += flip_write_bases()
     # X reads of K-tile t + 1
     g = b2 + 1
@@ -260,7 +284,10 @@ def emit(path):
     for hh in range(2):
         macro("O2_W4_CSTAGE%d" % hh, gen_cstage(hh))
     for name, (a_kc, b_kc) in FORMS.items():
-        macro("O2_W4_ASM_%s" % name, gen(a_kc, b_kc, BASE))
+        cfg = dict(BASE)
+        if cfg.get("kwrap_tn"):                  # (ablation restricted to the weight-gradient form: a step's activations stay right)
+            cfg["kwrap"] = cfg["kwrap_tn"] if name == "TN" else 0
+        macro("O2_W4_ASM_%s" % name, gen(a_kc, b_kc, cfg))
         macro("O2_W4_ASM_%s_STAMP" % name, gen(a_kc, b_kc, dict(BASE, stamp=True)))
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"a%d"' % r for r in range(256)] + ['"v%d"' % r for r in range(128, 256)] + \
            ['"s%d"' % r for r in range(64, 100)]
