@@ -399,10 +399,7 @@ def main():
     drop = 0.0 if a.no_dropout else 0.1
     tp = a.tensor_par
     capturable = world == 1 or os.environ.get("ORBIT2_DIST_BACKEND", "nccl") == "nccl"     # gloo rehearsals cannot be captured
-    # (the parameter-sharding engine stays eager: capturing its cross-stream gather / release pattern was tried in round 3 and
-    #  hipStreamEndCapture crashes on it -- DESIGN 5)
-    if a.fsdp and a.graph == "on":
-        raise SystemExit("--fsdp runs without hipGraph replay")
+    # (the parameter-sharding engine is captured on request only -- `--fsdp --graph on` -- in its single-stream form: DESIGN 5)
     a.graph = a.graph == "on" or (a.graph == "auto" and B * L <= 16384 and tp == 1 and capturable and not a.fsdp)
     if tp > 1 and (world % tp or a.graph):
         raise SystemExit("--tensor-par %d needs WORLD_SIZE divisible by it and no --graph" % tp)

@@ -212,11 +212,13 @@ def main():
         tokens = batch_size * (in_shape[2] // mc["patch_size"]) * (in_shape[3] // mc["patch_size"])
         capturable = world_size == 1 or dist.get_backend() == "nccl"      # gloo rehearsals stage through the host: no capture
         capturable = capturable and getattr(train_loss, "graph_capturable", True)
-        capturable = capturable and not getattr(eng, "shard_params", False)    # gathers / releases: hipStreamEndCapture crashes on them
+        # the parameter-sharding engine is captured in its single-stream form (round 6: fsdp_engine.single_stream) --
+        # on request only (`hipgraph: true`): `auto` keeps it eager, its models are not launch-bound
+        sharded = getattr(eng, "shard_params", False)
         if hg is True and (tp > 1 or not capturable):
-            raise ValueError("trainer.hipgraph: true is not available here (tensor parallelism, the parameter-sharding engine or a "
-                             "gloo rehearsal): use 'auto' or false")     # never a silent fallback
-        use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable)) and tp == 1
+            raise ValueError("trainer.hipgraph: true is not available here (tensor parallelism or a gloo rehearsal): use 'auto' or "
+                             "false")     # never a silent fallback
+        use_graph = (hg is True or (hg == "auto" and tokens <= 16384 and capturable and not sharded)) and tp == 1
         gstep, gshape = None, None
         for epoch in range(epoch_start, max_epochs):
             eng.train()

@@ -65,6 +65,36 @@ class HipFullyShardedDataParallel(nn.Module):
             raise RuntimeError("comm_stats cannot be switched on while a hipGraph capture of this engine's step exists "
                                "(GraphedTrainStep): captured events carry no timestamps")
         self.__dict__["_comm_stats"] = v
+
+    # The communication stream.  In SINGLE-STREAM mode (`single_stream()`, switched on by GraphedTrainStep) the property reads
+    # None and every `if self.comm_stream is not None` below takes the plain path: gathers, reduce-scatters and buffer hand-overs
+    # are queued on the caller's stream in program order, no cross-stream event is created.  That is the form a hipGraph capture of
+    # this engine's step takes: the two-stream form records ~4 fork / join edges PER UNIT in both directions between the capturing
+    # stream and the communication stream (pool-release event -> gather, gather-done event -> compute, gradient-ready event ->
+    # reduce-scatter, reduce-scatter-done event -> next user of the buffer), every one of them event-joined before the step ends
+    # (list in DESIGN 5) -- and hipStreamEndCapture segfaulted on it in rounds 3 and 5.  A replayed graph of a launch-bound step
+    # gains nothing from a second stream (its collectives are microseconds), so the capture does without.
+    @property
+    def comm_stream(self):
+        return None if self.__dict__.get("_o2_single_stream", False) else self.__dict__.get("_comm_stream")
+
+    @comm_stream.setter
+    def comm_stream(self, v):
+        self.__dict__["_comm_stream"] = v
+
+    def single_stream(self, on: bool = True):
+        """queue the engine's communication on the caller's stream from now on (see `comm_stream`); call between steps"""
+        real = self.__dict__.get("_comm_stream")
+        if real is not None:                            # nothing of an earlier two-stream step may still be in flight
+            torch.cuda.current_stream().wait_stream(real)
+            real.wait_stream(torch.cuda.current_stream())
+        if any(u.pbuf is not None or u.gbuf is not None for u in self.sharded_units):
+            raise RuntimeError("single_stream(): a unit still holds a pooled buffer -- call it between steps")
+        self._pfree_ev = [None] * len(self._pfree_ev)
+        self._gfree_ev = [None, None]
+        for u in self.units:
+            u.pevent = None
+        self.__dict__["_o2_single_stream"] = bool(on)
     def __init__(self, module: nn.Module, process_group=None, unit_types: Tuple[type, ...] = (), is_lowp=None,
                  sync_module_states: bool = True, replicate_group=None, prefetch: bool = True, pool_size: int = 3,
                  tp_group=None):

@@ -48,6 +48,27 @@ def _quiesce_collectives(device):
         torch.cuda.synchronize(device)
 
 
+# The seed salt is ONE word per device (include/orbit2_hip.h: orbit2_seed_salt): two engines replaying captured steps on one
+# device would advance each other's masks -- each replay still agrees with itself (forward and backward of a replay read the
+# same salt), but "the n-th replay of engine A draws mask n" no longer holds, and an eager step of A between two replays of B
+# sees B's salt.  The restriction was only documented; it is asserted here: a second LIVE engine with a captured
+# step on the same device is refused unless ORBIT2_ALLOW_SHARED_SALT=1 says the caller accepts interleaved mask sequences.
+_GRAPHED_ENGINES = {}        # device index -> weakref to the engine that owns the device's salt
+
+
+def _claim_salt(engine, device):
+    import os
+    import weakref
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ref = _GRAPHED_ENGINES.get(idx)
+    cur = ref() if ref is not None else None
+    if cur is not None and cur is not engine and os.environ.get("ORBIT2_ALLOW_SHARED_SALT", "0") != "1":
+        raise RuntimeError("GraphedTrainStep: another engine already replays a captured step on cuda:%d and the dropout seed salt "
+                           "is one word per device (orbit2_seed_salt): their mask sequences would interleave.  Drop the other "
+                           "engine, or set ORBIT2_ALLOW_SHARED_SALT=1 to accept that" % idx)
+    _GRAPHED_ENGINES[idx] = weakref.ref(engine)
+
+
 class GraphedTrainStep:
     def __init__(self, engine, loss_metric, batch, var_weights, scaler=None, warmup: int = 2):
         x, y, self.in_vars, self.out_vars = batch
@@ -55,15 +76,15 @@ class GraphedTrainStep:
             raise NotImplementedError("GraphedTrainStep covers the data-parallel step; tensor-parallel steps (large "
                                       "models, not launch-bound) run eagerly")
         if getattr(engine, "shard_params", False):
-            # The parameter-sharding engine is eager-only.  Its step does record into a capture (per-unit all-gathers, pooled
-            # buffers, reduce-scatters, cross-stream hand-over events), but hipStreamEndCapture then segfaults inside the runtime
-            # -- in round 3, and again in round 5 with every pool event of the uncaptured warm-up forgotten before the capture so
-            # that each wait followed a record made inside it.  It exists for models whose parameters do not fit a
-            # GPU replicated; those are not launch-bound, which is all a replayed graph buys.
-            raise NotImplementedError("GraphedTrainStep: the parameter-sharding engine (HipFullyShardedDataParallel) runs eagerly; "
-                                      "use HipDataParallel (optionally shard_optimizer=True) for a captured step")
+            # The parameter-sharding engine is captured in its SINGLE-STREAM form (fsdp_engine.single_stream): per-unit all-gathers,
+            # reduce-scatters and pooled-buffer hand-overs in program order on the capturing stream.  Its two-stream form records
+            # into a capture but hipStreamEndCapture segfaulted on the result in rounds 3 and 5 (DESIGN 5 lists every fork / join
+            # edge of that form; all are event-joined before the step ends, so the runtime, not an unjoined stream, is at fault).
+            engine.single_stream(True)
         self.engine, self.loss_metric, self.var_weights, self.scaler = engine, loss_metric, var_weights, scaler
         self.device = engine.device
+        if self.device.type == "cuda":
+            _claim_salt(engine, self.device)
         self.x = x.to(self.device).clone()           # static input buffers: refill with .copy_ between replays
         self.y = y.to(self.device).clone()
         self.warmup = warmup

@@ -343,6 +343,44 @@ __device__ __forceinline__ int xcd_round_tile_id() {
   const int q8 = cnt >> 3, r8 = cnt & 7;
   return base + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + s;
 }
+// Start barrier of a round's XCD cohort (long contractions only: the weight-gradient launch, 2048 K-tiles per tile).  Within a
+// round the 32 workgroups of an XCD keep step by themselves -- same instruction stream, same clock -- and fetch every strip
+// K-tile ONCE beyond L2 (profiles/r06_l2_share_probe.txt: one round = 1.00-1.01 x the ideal bytes at any K).  What breaks the
+// sharing is the round change: the next round's workgroups start as CUs fall free, microseconds apart, L2 holds ~10 K-tiles
+// (12 us) of a cohort's 12 strips, and a workgroup that starts outside that window re-fetches its strips for the whole sweep
+// (three rounds: 1.19 x; the Block's grouped launch, 6.75 rounds: 1.7 x = 80 GB for 48).  So a workgroup waits at its tile's
+// start until its cohort (round b >> 8, XCD b & 7) has assembled: a sense-reversing counter pair per cohort in a static device
+// array, self-cleaning (the last arriver zeroes the count and bumps the generation), polled by one lane with s_sleep between
+// agent-scope loads, BOUNDED (~15 us): it is a pacing hint, never needed for correctness -- a cohort that does not assemble
+// (another stream's kernel holding CUs) costs its workgroups the bound once per 2.7 ms tile.
+#define O2_W4_SYNC_SLOTS 512
+static __device__ unsigned int o2_w4_sync[2 * O2_W4_SYNC_SLOTS];       // [slot] = arrivals, [SLOTS + slot] = generation
+__device__ __forceinline__ void w4_cohort_start() {
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int base = b & ~255, x = b & 7;
+  const int cnt = (nwg - base) < 256 ? (nwg - base) : 256;
+  const int n = (cnt >> 3) + (x < (cnt & 7) ? 1 : 0);               // workgroups of this round on this XCD
+  const int slot = ((b >> 8) << 3) + x;
+  if (slot < O2_W4_SYNC_SLOTS && n > 1) {
+    if (threadIdx.x == 0) {
+      unsigned int* cntp = o2_w4_sync + slot;
+      unsigned int* genp = o2_w4_sync + O2_W4_SYNC_SLOTS + slot;
+      const unsigned int g0 = __hip_atomic_load(genp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int old = __hip_atomic_fetch_add(cntp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u >= (unsigned int)n) {
+        __hip_atomic_store(cntp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(genp, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (int polls = 0; polls < 56; ++polls) {
+          if (__hip_atomic_load(genp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g0) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 #ifndef O2_W4_WALK
 #define O2_W4_WALK 1        // 1: round-major ids for the 4-wave kernels; 0: the contiguous-range-per-XCD ids of rounds 2-5 (A/B builds)
 #endif
@@ -448,6 +486,7 @@ struct GProb {
 };
 struct GArgs {
   int n;
+  int pace;        // 4-wave kernel: cohort start barrier (w4_cohort_start) -- long contractions, round-major ids
   GProb p[ORBIT2_GEMM_MAX_GROUP];
 };
 
@@ -773,6 +812,18 @@ extern "C" int orbit2_debug_read_w4(unsigned int* host_dst, int n) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(o2_dbg_w4), sizeof(unsigned) * (size_t)n);
 }
 #endif
+#ifdef O2_W4_TRACE
+// diagnostic build only (tools/w4_trace.py): when did each workgroup start its K sweep and when did it end it -- s_memrealtime
+// (100 MHz) of wave 0 at the statement's entry and exit, [blockIdx][2]: the start spread of a round's XCD cohort and the drift
+// between its workgroups over a sweep
+__device__ unsigned long long o2_w4_trace[8192 * 2];
+extern "C" int orbit2_debug_read_w4_trace(unsigned long long* host_dst, int n) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(o2_w4_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#define O2_W4_TRACE_POINT(k) if (tid == 0 && blockIdx.x < 8192) o2_w4_trace[blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define O2_W4_TRACE_POINT(k)
+#endif
 // Epilogue of the 4-wave kernel: the accumulators go through LDS (free once the main loop is over) as an fp32 image of
 // 128 tile rows x 256 columns (two passes: accumulator rows i = 0..3, then 4..7 of every wave), written straight from the
 // accumulator registers (ds_write_b128 a[..], 16-byte chunk c of image row r stored at c ^ (r & 7): conflict-free writes and
@@ -924,6 +975,7 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
                [abase] "s"(abase), [bbase] "s"(bbase), [pa0] "s"(pa0), [psa] "s"(psa), [pha] "s"(pha), [pb0] "s"(pb0),       \
                [psb] "s"(psb), [phb] "s"(phb), [ldswa] "s"(ldswa), [ldswb] "s"(ldswb), [nk] "s"(nk), [ka] "s"(ka),       \
                [kb] "s"(kb), [ta0] "v"(ta0), [ta1] "v"(ta1), [tb0] "v"(tb0), [tb1] "v"(tb1)
+  O2_W4_TRACE_POINT(0);
   if constexpr (!STAMP) {
 #define O2_W4_RUN(STR)                                                                                                   \
   asm volatile(STR                                                                                                       \
@@ -936,6 +988,7 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
     if constexpr (FORM == 3) O2_W4_RUN(O2_W4_ASM_TT);
 #undef O2_W4_RUN
   }
+  O2_W4_TRACE_POINT(1);
 #ifdef O2_W4_STAMP
   if constexpr (STAMP) {
     unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -1096,6 +1149,7 @@ template <int FORM>
 __global__ __launch_bounds__(256, 1) void gemm256w_grouped_kernel(GArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
   const int id = w4_tile_id();
+  if (g.pace) w4_cohort_start();
   int pi = 0;
   while (pi + 1 < g.n && id >= g.p[pi].tile_end) ++pi;
   const int first = pi ? g.p[pi - 1].tile_end : 0;
@@ -1263,6 +1317,7 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
     if (args[i].colsum_ws) return O2_ERR_UNSUPPORTED;      // single launches only (orbit2_gemm_bf16_colsum_rows)
   GArgs g;
   g.n = n;
+  g.pace = 0;
   // 256-tile 8-phase kernel when every problem of the group can take it and the group fills the chip; 128-tile otherwise
   bool big = args[0].tile_hint != 128;
   long t256 = 0;
@@ -1292,6 +1347,12 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
     for (int i = 0; i < n; ++i) whole = whole && args[i].M % 256 == 0 && args[i].N % 256 == 0;
     if (whole) {
       dim3 grid(total), block(256);
+      // cohort start barrier: every problem's tiles sweep >= 512 K-tiles (a round lasts >= 0.6 ms: the bounded wait is noise
+      // against it, and a lost cohort costs a whole sweep of re-fetched strips)
+      static const int pace_env = [] { const char* e = getenv("ORBIT2_W4_PACE"); return e ? atoi(e) : 1; }();
+      int kmin = args[0].K;
+      for (int i = 1; i < n; ++i) kmin = args[i].K < kmin ? args[i].K : kmin;
+      g.pace = (O2_W4_WALK && pace_env && kmin >= 512 * BK3 && total > 256) ? 1 : 0;
       if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<0>), grid, block, 0, s, g);
       else if (args[0].a_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<1>), grid, block, 0, s, g);
       else if (args[0].b_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<3>), grid, block, 0, s, g);

@@ -167,17 +167,62 @@ def child_fully_sharded_engine_matches_replicated_engine(golden_dir):
             dist.destroy_process_group()
 
 
-def test_graphed_step_refuses_the_parameter_sharding_engine(golden_dir):
-    """the FULL_SHARD engine is eager-only (its capture crashes in hipStreamEndCapture): asking for a captured step
-    is an error at construction, not a crash at capture"""
+def test_graphed_step_of_the_parameter_sharding_engine(golden_dir):
+    run_child(__file__, "child_graphed_step_of_the_parameter_sharding_engine", golden_dir)
+
+
+def child_graphed_step_of_the_parameter_sharding_engine(golden_dir):
+    """The FULL_SHARD engine's step in a hipGraph (single-stream form: DESIGN 5, fsdp_engine.single_stream), collectives forced on
+    over a single-rank RCCL group: the capture ends without the hipStreamEndCapture fault of rounds 3 / 5, the first replay
+    reproduces the eager two-stream step with the same seeds and salt bit for bit (loss and every reduced gradient chunk), and
+    training through the graph + eager scaler / chunked AdamW descends with every pooled buffer back in its pool."""
+    import torch.distributed as dist
     import torch.nn as nn
     import climate_learn as cl
-    from climate_learn.graphs import GraphedTrainStep
+    from climate_learn import _hip, _ops
+    from climate_learn.graphs import GraphedTrainStep, SALT_STEP
     from climate_learn.metrics import Bayesian_TV
     from climate_learn.models.hub.components.vit_blocks import Block
+    from climate_learn.trainer import training_step
     from tests.test_model_gpu import load, VW
-    c, z, sd, m = load(golden_dir, "v5c1_hd64")
-    eng = cl.HipFullyShardedDataParallel(m.train(), unit_types=(Block, nn.Sequential))
-    batch = (torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), c["in_vars"], c["out_vars"])
-    with pytest.raises(NotImplementedError, match="runs eagerly"):
-        GraphedTrainStep(eng, Bayesian_TV(aggregate_only=True), batch, VW)
+    os.environ.update(ORBIT2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        def fresh():
+            c, z, sd, m = load(golden_dir, "v5c1_hd64")
+            eng = cl.HipFullyShardedDataParallel(m.train(), unit_types=(Block, nn.Sequential))
+            return c, z, eng
+        loss_fn = Bayesian_TV(aggregate_only=True)
+        c, z, eng_e = fresh()
+        batch = (torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), c["in_vars"], c["out_vars"])
+        cl.manual_seed(5)
+        mark = _ops.seeds.mark()
+        _hip.seed_salt(3 * SALT_STEP, add=False)       # what the first replay sees: 2 warm-up bumps + its own
+        eng_e.zero_grad()
+        le = training_step(batch, 0, eng_e, torch.device("cuda"), VW, loss_fn)
+        (le * 64.0).backward()
+        eng_e.finish_grad_sync()
+        g_e = eng_e.gchunk16.clone()
+        c, z, eng_g = fresh()
+        cl.manual_seed(5)
+        assert _ops.seeds.mark() == mark
+        _hip.seed_salt(0, add=False)
+        scaler = cl.HipGradScaler(init_scale=64.0, growth_interval=1000)
+        step = GraphedTrainStep(eng_g, loss_fn, batch, VW, scaler=scaler)
+        l1 = step().clone()
+        assert step.captures == 1 and eng_g.comm_stream is None
+        assert float(l1) == float(le) and torch.equal(eng_g.gchunk16, g_e)
+        opt = cl.load_optimizer(eng_g, "adamw", {"lr": 1e-3, "betas": (0.9, 0.99), "weight_decay": 1e-5})
+        traj = []
+        for _ in range(6):
+            traj.append(float(step()))
+            scaler.step(opt)
+            scaler.update()
+        assert step.captures == 1 and traj[-1] < traj[0], traj
+        assert len(eng_g._pfree) == 3 and len(eng_g._gfree) == 2
+    finally:
+        _hip.seed_salt(0, add=False)
+        if created:
+            dist.destroy_process_group()

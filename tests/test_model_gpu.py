@@ -271,6 +271,9 @@ def child_graphed_step_matches_eager_and_draws_new_masks():
             scaler.step(opt)
             scaler.update()
         assert step.captures == 1 and traj[-1] < traj[0]
+        # the seed salt is one word per device: a second live engine with a captured step on it is refused
+        with pytest.raises(RuntimeError, match="one word per device"):
+            GraphedTrainStep(eng_e, loss_fn, batch, vw)
     finally:
         _hip.seed_salt(0, add=False)
 
