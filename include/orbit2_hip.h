@@ -82,7 +82,7 @@ int orbit2_gemm_bf16_colsum_rows(const orbit2_gemm_args* args);   /* 0: this cal
  * 8-phase kernel when every problem has K % 64 == 0, M, N >= 256 and the group fills the chip; the 128x128 kernel
  * otherwise): the partially filled last round of each problem is filled with the next one's tiles.  Used for
  * the four weight-gradient GEMMs of a Block (reference: autograd of attention.py:36,40 + mlp.py:50,54). */
-#define ORBIT2_GEMM_MAX_GROUP 8
+#define ORBIT2_GEMM_MAX_GROUP 12
 int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream);
 
 /* small fp32 GEMM (parameter-table algebra of the folded variable aggregation):

@@ -173,7 +173,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, want_colsum=False, **kw):
     return (out, parts) if want_colsum else out
 
 
-GEMM_MAX_GROUP = 8
+GEMM_MAX_GROUP = 12
 
 
 def gemm_grouped(problems):

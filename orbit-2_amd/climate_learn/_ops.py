@@ -173,7 +173,11 @@ def _ld_pad(n: int) -> int:
     put the same k-offset of EVERY row on the same memory channel (the MLP hidden tensors of interm_1b: 24 KiB rows) and the
     LDS-DMA pieces of a GEMM, 4-8 rows each, queue on it: -13 % on the weight-gradient GEMMs that read them K-strided, -20 % on
     a K-contiguous 4-wave GEMM (profiles/r03_gemm_ld_pad.txt).  128 bytes of padding per row spread them."""
-    return n + 64 if (2 * n) % 8192 == 0 else n
+    return n + 64 if (2 * n) % _LD_PAD_MOD == 0 else n
+
+
+import os as _os
+_LD_PAD_MOD = int(_os.environ.get("ORBIT2_LD_PAD_MOD", "8192"))
 
 
 def _ld(t, n):
@@ -241,6 +245,72 @@ def _dw(dy2d, x2d, W, b, M, N, K):
     return gw, gb
 
 
+_DW_BALANCE = int(_os.environ.get("ORBIT2_DW_BALANCE", "4"))      # K-split of the tail tiles of a grouped weight-gradient launch (0: off)
+
+
+def _dw_balance_plan(shapes, S, slots=256):
+    """shapes: [(tiles_m, tiles_n)] of the group's problems.  A grouped launch of T tiles on `slots` workgroup slots (one 256 x 256
+    tile per CU) takes ceil(T / slots) sweeps of the contraction; the last one runs T % slots tiles on a partly idle chip (the
+    Block's four weight gradients at interm_1b: 1728 tiles = 6.75 rounds, 7 sweeps paid).  Plan: R = T % slots tiles leave the
+    full-length set -- whole problems, smallest first, then whole tile rows of the next one -- and are split S ways over the
+    tokens: F = T - R full tiles fill whole rounds, the R x S part-length units (R x S a multiple of `slots`) fill whole rounds of
+    1 / S the length.  Returns [(problem index, first tile row, tile rows)] to split, or None when no exact plan exists."""
+    T = sum(tm * tn for tm, tn in shapes)
+    R = T % slots
+    if S < 2 or R == 0 or T < slots or (R * S) % slots:
+        return None
+    order = sorted(range(len(shapes)), key=lambda i: shapes[i][0] * shapes[i][1])
+    plan, need = [], R
+    for i in order:
+        tm, tn = shapes[i]
+        if need == 0:
+            break
+        if tm * tn <= need:
+            plan.append((i, 0, tm))
+            need -= tm * tn
+        elif need % tn == 0:
+            r = need // tn
+            plan.append((i, tm - r, r))          # the LAST tile rows of the problem
+            need = 0
+    return plan if need == 0 else None
+
+
+def _dw_balance(problems):
+    """(problems for ONE grouped launch, [(parts, S, rows, K, destination rows, beta)] to sum afterwards): see _dw_balance_plan.
+    Applies to whole-tile bf16 problems over one long token range; anything else is returned unchanged."""
+    S = _DW_BALANCE
+    if S < 2 or len(problems) < 2:
+        return problems, []
+    M = problems[0][5]
+    ok = all(p[5] == M and p[3] % 256 == 0 and p[4] % 256 == 0 and p[2].dtype == BF and p[0].dim() == 2 and p[1].dim() == 2
+             for p in problems) and M % (S * 64) == 0 and M // S >= 32768
+    if not ok:
+        return problems, []
+    plan = _dw_balance_plan([(p[3] // 256, p[4] // 256) for p in problems], S)
+    if plan is None:
+        return problems, []
+    full, split, sums = [], [[] for _ in range(S)], []
+    cut = {i: (r0, r) for i, r0, r in plan}
+    Mc = M // S
+    for i, (dy, x, out, N, K, M_, lda, ldb, ldc, kw) in enumerate(problems):
+        if i not in cut:
+            full.append(problems[i])
+            continue
+        r0, r = cut[i]
+        n0, n1 = 256 * r0, 256 * (r0 + r)
+        if r0 > 0:                                   # the problem's first tile rows stay full-length
+            full.append((dy[:, :n0], x, out[:n0], n0, K, M_, lda, ldb, ldc, kw))
+        parts = torch.empty(S, n1 - n0, K, dtype=BF, device=dy.device)      # bf16 partials, summed in fp32 by orbit2_batch_sum
+        for q in range(S):
+            split[q].append((dy[q * Mc:(q + 1) * Mc, n0:n1], x[q * Mc:(q + 1) * Mc], parts[q], n1 - n0, K, Mc, lda, ldb, K,
+                             dict(a_kc=False, b_kc=False)))
+        sums.append((parts, S, n1 - n0, K, out[n0:n1], kw.get("beta", 0.0)))
+    probs = full + [u for q in range(S) for u in split[q]]       # full-length tiles first (whole rounds), then slice by slice
+    if len(probs) > _hip.GEMM_MAX_GROUP:
+        return problems, []
+    return probs, sums
+
+
 class _DwBatch:
     """Weight-gradient GEMMs of one autograd node, deferred and issued as ONE grouped launch: the last, partially
     filled round of workgroups of each problem is filled by the next problem's tiles (dW grids are small: the
@@ -268,8 +338,11 @@ class _DwBatch:
 
     def flush(self):
         """launches the group; returns the per-problem values backward must return for the weights"""
-        for i in range(0, len(self.problems), _hip.GEMM_MAX_GROUP):     # the whole node as ONE grouped launch
-            _hip.gemm_grouped(self.problems[i:i + _hip.GEMM_MAX_GROUP])
+        probs, sums = _dw_balance(self.problems)
+        for i in range(0, len(probs), _hip.GEMM_MAX_GROUP):     # the whole node as ONE grouped launch
+            _hip.gemm_grouped(probs[i:i + _hip.GEMM_MAX_GROUP])
+        for parts, S, rows, K, dst, beta in sums:               # the split tiles' partial products, summed in a fixed order
+            _hip.batch_sum(parts, S, rows, K, dst, beta=beta)
         out = [s.done() for s in self.sinks]
         self.problems, self.sinks, self.keep = [], [], []
         return out

@@ -161,3 +161,21 @@ def test_shape_tolerant_pretrain_load(tmp_path):
     torch.save({"epoch": 3, "model_state_dict": {k: v for k, v in sd.items() if k != "extra.not_in_model"}}, path)
     ck = load_checkpoint(pre, path)
     assert ck["epoch"] == 3 and torch.equal(pre.state_dict()["head.0.weight"], sd["head.0.weight"])
+
+
+def test_weight_gradient_group_balance_plan():
+    """host logic of the balanced grouped weight-gradient launch (_ops._dw_balance_plan): the tiles beyond the last whole round
+    of 256 leave the full-length set as whole problems / whole tile rows and are split over the tokens so that both parts fill
+    whole rounds; no exact plan -> None (the launch stays as it was)"""
+    from climate_learn._ops import _dw_balance_plan
+    # interm_1b Block: qkv 36 x 12, proj 12 x 12, fc1 48 x 12, fc2 12 x 48 = 1728 tiles = 6.75 rounds
+    shapes = [(36, 12), (12, 12), (48, 12), (12, 48)]
+    plan = _dw_balance_plan(shapes, 4)
+    assert plan == [(1, 0, 12), (0, 32, 4)]                       # all of proj (144) + the last 4 tile rows of qkv (48) = 192
+    cut = sum(r * shapes[i][1] for i, _, r in plan)
+    total = sum(a * b for a, b in shapes)
+    assert cut == total % 256 and (total - cut) % 256 == 0 and (cut * 4) % 256 == 0
+    assert _dw_balance_plan(shapes, 2) is None                    # 192 x 2 is not a whole number of rounds
+    assert _dw_balance_plan([(4, 4), (4, 4)], 4) is None          # fewer tiles than one round
+    assert _dw_balance_plan([(16, 16)], 4) is None                # already whole rounds
+    assert _dw_balance_plan([(36, 12), (12, 12), (48, 12), (12, 48)], 0) is None
