@@ -58,6 +58,13 @@ def parse():
                     help="per-GPU batch: 16 (1 / 2 / 4 / 8 / 16 / 32 all fit one GPU; 8 is 1 % slower, 32 = the reference "
                          "YAML's batch_size gives the same rate at twice the step time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "npz"],
+                    help="npz: after the resident-batch measurement, the SAME step fed through the reference-format data plane "
+                         "(a synthesized <root>/{train}/<year>_<shard>.npz tree at the run's grids -> climate_learn.data.IterDataModule "
+                         ".train_dataloader() with worker processes and pinned batches -> non_blocking uploads); attached as `data_npz`")
+    ap.add_argument("--data-workers", type=int, default=8)
+    ap.add_argument("--other-configs-smoke", action="store_true",
+                    help="tests: attach `other_configs` to ANY single-GPU run, with one tiny child run (interm_8m) instead of the three")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the child runs of the other BASELINE configs (interm_117m 32x64 batch 8, the Daymet-like interm_1b "
                          "step, interm_10b batch 2) that the default single-GPU run attaches as `other_configs`")
@@ -257,14 +264,105 @@ OTHER_CONFIGS = (
 )
 
 
-def other_configs(t_start, budget_s=420.0):
+def write_npz_tree(root, hw, variables, n_files, per_file, seed):
+    """a directory tree in the reference's on-disk format (data/processing/nc2npz.py:22-166 writes it there; reader:
+    data/iterdataset.py:46-177): <root>/train/<year>_<shard>.npz with var -> float32 [T, 1, H, W], lat.npy, lon.npy,
+    normalize_{mean,std}.npz, train/climatology.npz.  Values are the bench's synthetic recipe in physical units."""
+    rng = np.random.default_rng(seed)
+    H, W = hw
+    os.makedirs(os.path.join(root, "train"), exist_ok=True)
+    for f in range(n_files):
+        arrs = {}
+        for v in variables:
+            a = rng.standard_normal((per_file, 1, H, W), dtype=np.float32)
+            arrs[v] = (np.abs(a) * 1e-3) if "precip" in v else (a + 270.0)
+        np.savez(os.path.join(root, "train", "2000_%d.npz" % f), **arrs)
+    np.savez(os.path.join(root, "train", "climatology.npz"), **{v: np.zeros((1, H, W), np.float32) for v in variables})
+    np.save(os.path.join(root, "lat.npy"), np.linspace(-90.0, 90.0, H))
+    np.save(os.path.join(root, "lon.npy"), np.linspace(0.0, 360.0, W, endpoint=False))
+    np.savez(os.path.join(root, "normalize_mean.npz"), **{v: np.array([0.5e-3 if "precip" in v else 270.0]) for v in variables})
+    np.savez(os.path.join(root, "normalize_std.npz"), **{v: np.array([1e-3 if "precip" in v else 1.0]) for v in variables})
+
+
+def npz_leg(a, step_on, fence, in_vars, out_vars, lo_hw, hi_hw, B, resident_sps, dev):
+    """the step at the headline configuration fed END TO END through the npz data plane.  `step_on(batch, i)` runs
+    one full training step on a loader batch.  Reports samples/s beside the resident-batch figure, the loader's CPU seconds
+    per sample (one process, no GPU work: what a worker spends reading, normalising and collating one sample) and how long the
+    consumer waited for batches."""
+    import shutil
+    import tempfile
+    import climate_learn as cl
+    root = tempfile.mkdtemp(prefix="orbit2_npz_", dir=os.environ.get("ORBIT2_NPZ_DIR", "/tmp"))
+    try:
+        # one batch per shard file; every worker owns the same number of files and the whole measurement (warm-up + timed steps)
+        # stays inside ONE pass over the tree: a pass change tears the worker pool down and forks a new one from a process that
+        # maps > 100 GB of device memory (seconds; measured 13 s with 8 files and 10 batches) -- real trees hold years of shards per
+        # pass, so that cost is per epoch, not per few steps, and is not what this leg is about
+        wk = max(1, a.data_workers)
+        per_file, n_files = B, -(-(max(1, a.warmup) + a.steps + 2) // wk) * wk
+        t0 = time.perf_counter()
+        write_npz_tree(os.path.join(root, "lo"), lo_hw, in_vars, n_files, per_file, 1)
+        write_npz_tree(os.path.join(root, "hi"), hi_hw, out_vars, n_files, per_file, 2)
+        t_write = time.perf_counter() - t0
+        pin = os.environ.get("ORBIT2_NPZ_PIN", "1") == "1"
+        mk = lambda workers: cl.data.IterDataModule("downscaling", os.path.join(root, "lo"), os.path.join(root, "hi"), in_vars, out_vars,
+                                                    batch_size=B, buffer_size=0, num_workers=workers, pin_memory=pin)
+        dm0 = mk(0)
+        dm0.setup()
+        t0 = time.perf_counter()
+        n0 = 0
+        for bt in dm0.train_dataloader():                            # loader cost alone, one process
+            n0 += bt[0].shape[0]
+            if n0 >= 2 * B:
+                break
+        cpu_s_per_sample = (time.perf_counter() - t0) / max(n0, 1)
+        dm = mk(a.data_workers)
+        dm.setup()
+
+        def batches():
+            while True:                                              # epochs back to back (a fresh loader per epoch, as the driver does)
+                for bt in dm.train_dataloader():
+                    if bt[0].shape[0] == B:
+                        yield bt
+        it = batches()
+        for i in range(max(1, a.warmup)):
+            step_on(next(it), i)
+        fence()
+        waited = queued = 0.0
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            tw = time.perf_counter()
+            bt = next(it)
+            ts = time.perf_counter()
+            waited += ts - tw
+            step_on(bt, a.warmup + i)
+            queued += time.perf_counter() - ts
+        fence()
+        dt = time.perf_counter() - t0
+        sps = B * a.steps / dt
+        return {"value": sps, "unit": "samples/s", "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps,
+                "resident_value": resident_sps, "ratio_to_resident": sps / resident_sps,
+                "workers": a.data_workers, "pin_memory": pin, "host_ms_per_step_in_the_step_call": 1e3 * queued / a.steps, "upload": "non_blocking .to(device) of pinned batches (trainer.training_step)",
+                "loader_cpu_s_per_sample": cpu_s_per_sample,
+                "loader_cores_needed_at_this_rate": cpu_s_per_sample * sps,
+                "consumer_wait_ms_per_step": 1e3 * waited / a.steps,
+                "tree": {"format": "reference npz tree (nc2npz.py layout), float32", "low_res": list(lo_hw), "high_res": list(hi_hw),
+                         "files": n_files, "samples_per_file": per_file, "write_s": t_write,
+                         "bytes_per_sample": 4 * (len(in_vars) * lo_hw[0] * lo_hw[1] + len(out_vars) * hi_hw[0] * hi_hw[1])},
+                "path": "IterDataModule(inp_root_dir, out_root_dir).train_dataloader(): NpyReader file sharding -> Downscale -> "
+                        "Normalize / LogTransform -> collate_fn (data/iterdataset.py, itermodule.py)"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def other_configs(t_start, budget_s=420.0, configs=None):
     """The other BASELINE configs on the driver's clock: each one is this same script run as a CHILD process
     (a fresh interpreter started with subprocess after this process has released its device memory; never an exec of the
     process that holds the GPU), its JSON line reduced to {value, ms_per_step, roofline.frac, config}.  A config is skipped,
     and says so, when the time already spent plus its allowance would pass `budget_s` (the default run must stay within minutes)."""
     import subprocess
     out = {}
-    for key, what, args, allow in OTHER_CONFIGS:
+    for key, what, args, allow in (configs or OTHER_CONFIGS):
         spent = time.perf_counter() - t_start
         if spent + allow > budget_s:
             out[key] = {"skipped": "time budget: %.0f s spent, %d s allowance, %.0f s budget" % (spent, allow, budget_s), "stands_for": what}
@@ -632,8 +730,17 @@ def main():
                                if cst["comm_ms_per_step"] > 0 else None)
             out["comm_ms_per_step"] = cst["comm_ms_per_step"]
             out["exposed_comm_ms"] = cst["exposed_comm_ms_per_step"]
+        if a.data == "npz" and world == 1 and not a.graph:
+            def step_on(bt, i):
+                loss = training_step(bt, i, eng, dev, VAR_WEIGHTS, loss_fn)
+                opt.zero_grad()
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+            out["data_npz"] = npz_leg(a, step_on, fence, in_vars, OUT_VARS, (h, w), (hy, wy), B, sps, dev)
+            out["data"] = "synthetic, resident in HBM (`value`); `data_npz` = the same step fed from a reference-format npz tree"
         default_run = (a.model == "interm_1b" and a.grid == "128x256" and not a.daymet and tp == 1 and not a.fsdp and not a.recompute)
-        if world == 1 and (a.eager_baseline or not a.no_cpu_baseline or (default_run and not a.no_other_configs)):
+        if world == 1 and (a.eager_baseline or not a.no_cpu_baseline or (default_run and not a.no_other_configs) or a.other_configs_smoke):
             # release the headline run's device memory: the closures hold the engine, the optimizer and the batch too
             import gc as _gc
             step = fence = last = gstep = loss_fn = scaler = x = y = None          # noqa: F841
@@ -641,7 +748,11 @@ def main():
             _gc.collect()
             torch.cuda.empty_cache()
             print("[bench] released; device memory still allocated: %.1f GB" % (torch.cuda.memory_allocated() / 1e9), file=sys.stderr)
-        if world == 1 and default_run and not a.no_other_configs:
+        if world == 1 and a.other_configs_smoke:
+            out["other_configs"] = other_configs(T_PROCESS_START, configs=(
+                ("interm_8m_32x64_b2", "configs[0]-shaped smoke entry (tests)", ["--model", "interm_8m", "--grid", "32x64", "--batch", "2",
+                                                                                  "--steps", "3", "--warmup", "1"], 240),))
+        elif world == 1 and default_run and not a.no_other_configs:
             out["other_configs"] = other_configs(T_PROCESS_START)
         if world == 1 and a.eager_baseline and not a.daymet:
             out["gpu_eager_baseline"] = gpu_eager_baseline(a.model, V, C, a.eager_baseline, dev)

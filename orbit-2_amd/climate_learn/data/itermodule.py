@@ -101,6 +101,7 @@ class IterDataModule(SyntheticGridDataModule):
         self.inp_root_dir, self.out_root_dir = inp_root_dir, out_root_dir
         self.data_par_size, self.data_par_group = data_par_size, data_par_group
         self.subsample, self.buffer_size, self.num_workers = subsample, buffer_size, num_workers
+        self.pin_memory = bool(pin_memory)           # page-locked batches: the trainer's non_blocking uploads then run as DMA
         self.div, self.overlap = div, overlap
         self.on_disk = bool(inp_root_dir) and os.path.isdir(os.path.join(str(inp_root_dir), "train"))
         if self.on_disk:
@@ -180,7 +181,8 @@ class IterDataModule(SyntheticGridDataModule):
                 return super().__iter__()
 
         return _EpochLoader(ds, batch_size=self.batch_size, drop_last=False, num_workers=self.num_workers,
-                            collate_fn=ID.collate_fn)
+                            collate_fn=ID.collate_fn, pin_memory=self.pin_memory and torch.cuda.is_available(),
+                            persistent_workers=False)
 
     def train_dataloader(self):
         return self._loader("train", True) if self.on_disk else super().train_dataloader()

@@ -352,3 +352,26 @@ def test_bench_single_rank_line_with_baselines(tmp_path):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     ge = d["gpu_eager_baseline"]
     assert ge["value"] > 0 and ge["per_gpu_batch"] == 2
+
+
+def test_bench_other_configs_and_npz_leg(tmp_path):
+    """the line carries `other_configs` (each entry = a child run of this script reduced to value /
+    ms_per_step / roofline.frac / config) and, with --data npz, `data_npz` (the same step fed through the reference-format data
+    plane: samples/s beside the resident figure, loader CPU seconds per sample, workers)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--model", "interm_8m",
+                        "--grid", "32x64", "--batch", "2", "--no-cpu-baseline", "--other-configs-smoke", "--data", "npz",
+                        "--data-workers", "2", "--graph", "off"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    oc = d["other_configs"]
+    assert list(oc) == ["interm_8m_32x64_b2"]
+    e = oc["interm_8m_32x64_b2"]
+    assert "error" not in e and e["value"] > 0 and e["ms_per_step"] > 0 and 0 < e["roofline"]["frac"] < 1
+    assert "workload" in e["config"] and e["config"]["per_gpu_batch"] == 2 and e["command"].startswith("python bench.py --model interm_8m")
+    n = d["data_npz"]
+    assert n["value"] > 0 and n["resident_value"] == d["value"] and abs(n["ratio_to_resident"] - n["value"] / d["value"]) < 1e-9
+    assert n["workers"] == 2 and n["loader_cpu_s_per_sample"] > 0 and n["tree"]["low_res"] == [32, 64] and n["tree"]["high_res"] == [128, 256]
+    assert "npz" in d["data"]
