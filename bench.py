@@ -42,8 +42,8 @@ MODELS = {  # configs/interm_*.yaml of the reference
     "interm_10b": dict(embed_dim=8192, depth=11, num_heads=32),
 }
 PEAK_BF16 = 2.5e15   # dense MFMA peak, MI355X_MICROARCH.md
-MALL_JSON = "r05_mall_latency.json"  # Infinity-Cache share of that traffic (TCC_EA0_RDREQ_LEVEL pass of tools/mall_probe.py)
-TRAFFIC_JSON = "r05_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
+MALL_JSON = "r06_mall_latency.json"  # Infinity-Cache share of that traffic (TCC_EA0_RDREQ_LEVEL pass of tools/mall_probe.py)
+TRAFFIC_JSON = "r06_traffic.json"   # PMC passes (FETCH_SIZE / WRITE_SIZE) of the bench configuration, tools/profile_round.sh
 METRIC = "climate-grid samples/sec/node (fwd+bwd), interm_1b ERA5 1.4°→0.25°, 1/2/4/8 GPUs"
 
 

@@ -172,12 +172,20 @@ def _ld_pad(n: int) -> int:
     """row pitch (elements) of a [rows, n] bf16 activation that only GEMMs and column sums touch: rows a multiple of 8 KiB apart
     put the same k-offset of EVERY row on the same memory channel (the MLP hidden tensors of interm_1b: 24 KiB rows) and the
     LDS-DMA pieces of a GEMM, 4-8 rows each, queue on it: -13 % on the weight-gradient GEMMs that read them K-strided, -20 % on
-    a K-contiguous 4-wave GEMM (profiles/r03_gemm_ld_pad.txt).  128 bytes of padding per row spread them."""
+    a K-contiguous 4-wave GEMM (profiles/r03_gemm_ld_pad.txt).  128 bytes of padding per row spread them.
+    Round 6: the D-wide operands too (LayerNorm outputs, attention output: rows a multiple of 2 KiB apart, e.g. 6 KiB at D = 3072).
+    They are the N-side operand of the weight-gradient launch, whose 256-column strips are then served at different rates by the
+    memory side (strips at even multiples of 512 B sweep 3-5 % slower than their odd neighbours: profiles/r06_w4_trace_pace0.txt)
+    and a cohort's workgroups drift apart; padded, the launch is 1.8 % faster in the step and nothing else moves
+    (profiles/r06_ld_pad_small_instep.txt; padding the 3 D-wide qkv rows as well gave it back elsewhere: r06_ld_pad_instep.txt)."""
+    if _LD_PAD_SMALL and n < 4096 and (2 * n) % 2048 == 0:
+        return n + 64
     return n + 64 if (2 * n) % _LD_PAD_MOD == 0 else n
 
 
 import os as _os
 _LD_PAD_MOD = int(_os.environ.get("ORBIT2_LD_PAD_MOD", "8192"))
+_LD_PAD_SMALL = _os.environ.get("ORBIT2_LD_PAD_SMALL", "1") == "1"
 
 
 def _ld(t, n):

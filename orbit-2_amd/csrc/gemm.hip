@@ -354,8 +354,9 @@ __device__ __forceinline__ int xcd_round_tile_id() {
 // agent-scope loads, BOUNDED (~15 us): it is a pacing hint, never needed for correctness -- a cohort that does not assemble
 // (another stream's kernel holding CUs) costs its workgroups the bound once per 2.7 ms tile.
 #define O2_W4_SYNC_SLOTS 512
-static __device__ unsigned int o2_w4_sync[2 * O2_W4_SYNC_SLOTS];       // [slot] = arrivals, [SLOTS + slot] = generation
-__device__ __forceinline__ void w4_cohort_start() {
+static __device__ unsigned int o2_w4_sync[3 * O2_W4_SYNC_SLOTS];       // [slot] = arrivals, [SLOTS + slot] = generation,
+                                                                        // [2 SLOTS + slot] = arrivals at the in-sweep check points
+__device__ __forceinline__ const unsigned int* w4_cohort_start(int& n_out) {
   const int nwg = gridDim.x, b = blockIdx.x;
   const int base = b & ~255, x = b & 7;
   const int cnt = (nwg - base) < 256 ? (nwg - base) : 256;
@@ -367,6 +368,10 @@ __device__ __forceinline__ void w4_cohort_start() {
       unsigned int* genp = o2_w4_sync + O2_W4_SYNC_SLOTS + slot;
       const unsigned int g0 = __hip_atomic_load(genp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned int old = __hip_atomic_fetch_add(cntp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the FIRST arriver zeroes the sweep's check-point counter: nobody of this cohort can reach a check point (64 K-tiles =
+      // ~85 us into its sweep) before that, whereas the LAST arriver may come after a member that gave up waiting has already
+      // counted itself there
+      if (old == 0u) __hip_atomic_store(o2_w4_sync + 2 * O2_W4_SYNC_SLOTS + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old + 1u >= (unsigned int)n) {
         __hip_atomic_store(cntp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(genp, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -378,7 +383,11 @@ __device__ __forceinline__ void w4_cohort_start() {
       }
     }
     __syncthreads();
+    n_out = n;
+    return o2_w4_sync + 2 * O2_W4_SYNC_SLOTS + slot;
   }
+  n_out = 0;
+  return nullptr;
 }
 
 #ifndef O2_W4_WALK
@@ -909,7 +918,7 @@ __device__ __forceinline__ void w4_generic_finish(const Epi& epi, const char* sm
 template <int FORM, bool STAMP, int EK = 0>
 __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
                                               int K, int lda, int ldb, int tiles_m, int tiles_n, const Epi& epi, int id,
-                                              char* smem) {
+                                              char* smem, const unsigned int* pace_ctr = nullptr, int pace_n = 0) {
   constexpr bool A_KC = (FORM == 0 || FORM == 1), B_KC = (FORM == 0 || FORM == 3);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -932,6 +941,8 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   const int grp = id / per_group;
   const int first_g = grp * GROUP;
   const int gsz = (t_major - first_g) < GROUP ? (t_major - first_g) : GROUP;
+  // (measured and not kept, round 6: the minor index fastest inside 8-wide chunks -- four workgroups dispatched together then hold
+  // four different minor strips: the same time, 11 % more bytes fetched; profiles/r06_nfast_ab.txt, r06_w4_trace_nfast.txt)
   const int t_a = first_g + (id % per_group) % gsz;
   const int t_b = (id % per_group) / gsz;
   const int tm = tw ? t_b : t_a, tn = tw ? t_a : t_b;
@@ -971,10 +982,16 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
   const uint32_t ldswa = lds0 + wave * 4 * (A_KC ? 1024 : 1056);
   const uint32_t ldswb = lds0 + 2 * O2_W4_UNIT + wave * 4 * (B_KC ? 1024 : 1056);
   const uint32_t nk = (uint32_t)(K / BK3);
+  // cohort pacing inside the sweep (the TN statement only reads these): the counter's address for the ONE wave that arrives and
+  // polls on the workgroup's behalf, 0 for the others and for unpaced launches
+  const uint64_t pc64 = (wave == 0) ? (uint64_t)(uintptr_t)pace_ctr : 0ull;
+  const uint64_t pcp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pc64 >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pc64);          // (wave-uniform: SGPR operands)
+  const uint32_t pcn = (uint32_t)__builtin_amdgcn_readfirstlane(pace_n);
 #define O2_W4_OPERANDS                                                                                                   \
                [abase] "s"(abase), [bbase] "s"(bbase), [pa0] "s"(pa0), [psa] "s"(psa), [pha] "s"(pha), [pb0] "s"(pb0),       \
                [psb] "s"(psb), [phb] "s"(phb), [ldswa] "s"(ldswa), [ldswb] "s"(ldswb), [nk] "s"(nk), [ka] "s"(ka),       \
-               [kb] "s"(kb), [ta0] "v"(ta0), [ta1] "v"(ta1), [tb0] "v"(tb0), [tb1] "v"(tb1)
+               [kb] "s"(kb), [ta0] "v"(ta0), [ta1] "v"(ta1), [tb0] "v"(tb0), [tb1] "v"(tb1), [pcp] "s"(pcp), [pcn] "s"(pcn)
   O2_W4_TRACE_POINT(0);
   if constexpr (!STAMP) {
 #define O2_W4_RUN(STR)                                                                                                   \
@@ -1149,13 +1166,15 @@ template <int FORM>
 __global__ __launch_bounds__(256, 1) void gemm256w_grouped_kernel(GArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[8 * O2_W4_UNIT];
   const int id = w4_tile_id();
-  if (g.pace) w4_cohort_start();
+  int pace_n = 0;
+  const unsigned int* pace_ctr = g.pace ? w4_cohort_start(pace_n) : nullptr;
+  if (g.pace < 2) pace_ctr = nullptr;                                   // pace 1: the start barrier only
   int pi = 0;
   while (pi + 1 < g.n && id >= g.p[pi].tile_end) ++pi;
   const int first = pi ? g.p[pi - 1].tile_end : 0;
   const GProb& P = g.p[pi];
   const Epi epi = P.epi;
-  gemm256w_tile<FORM, false>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem);
+  gemm256w_tile<FORM, false>(P.A, P.B, P.M, P.N, P.K, P.lda, P.ldb, P.tiles_m, P.tiles_n, epi, id - first, smem, pace_ctr, pace_n);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1349,10 +1368,10 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
       dim3 grid(total), block(256);
       // cohort start barrier: every problem's tiles sweep >= 512 K-tiles (a round lasts >= 0.6 ms: the bounded wait is noise
       // against it, and a lost cohort costs a whole sweep of re-fetched strips)
-      static const int pace_env = [] { const char* e = getenv("ORBIT2_W4_PACE"); return e ? atoi(e) : 1; }();
+      static const int pace_env = [] { const char* e = getenv("ORBIT2_W4_PACE"); return e ? atoi(e) : 2; }();   // 0 off, 1 start barrier, 2 + in-sweep
       int kmin = args[0].K;
       for (int i = 1; i < n; ++i) kmin = args[i].K < kmin ? args[i].K : kmin;
-      g.pace = (O2_W4_WALK && pace_env && kmin >= 512 * BK3 && total > 256) ? 1 : 0;
+      g.pace = (O2_W4_WALK && pace_env && kmin >= 512 * BK3 && total > 256) ? pace_env : 0;
       if (args[0].a_kc && args[0].b_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<0>), grid, block, 0, s, g);
       else if (args[0].a_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<1>), grid, block, 0, s, g);
       else if (args[0].b_kc) hipLaunchKernelGGL((gemm256w_grouped_kernel<3>), grid, block, 0, s, g);

@@ -618,11 +618,14 @@ def test_block_padded_hidden_pitch_is_bit_identical(monkeypatch, dim, heads):
     the same bits, forward and every gradient, with the padding switched off -- train mode (GELU + dropout + DropPath epilogues,
     the weight-gradient group reading the padded tensors K-strided), and under activation recompute.  At width 4096 (the
     interm_10b case, D % 4096 == 0) the LayerNorm outputs and the attention output are padded too (orbit2_layernorm_fwd_ld,
-    orbit2_attn_fwd_ld / _bwd_ld): head dimension 128 runs the generated attention kernels, 256 the compiler-scheduled ones"""
+    orbit2_attn_fwd_ld / _bwd_ld): head dimension 128 runs the generated attention kernels, 256 the compiler-scheduled ones.
+    Round 6 pads the D-wide operands at every D that is a multiple of 1024 (width 1024, head dimension 64, here)"""
     import climate_learn as cl
     from climate_learn import _ops
     from climate_learn.models.hub.components.vit_blocks import Block
-    assert _ops._ld_pad(4096) == 4096 + 64 and _ops._ld_pad(12288) == 12288 + 64 and _ops._ld_pad(3072) == 3072
+    # (round 6: the D-wide operands are padded too -- rows a multiple of 2 KiB apart below 4096 columns; the 3 D-wide qkv rows are not)
+    assert _ops._ld_pad(4096) == 4096 + 64 and _ops._ld_pad(12288) == 12288 + 64 and _ops._ld_pad(3072) == 3072 + 64
+    assert _ops._ld_pad(1024) == 1024 + 64 and _ops._ld_pad(9216) == 9216 and _ops._ld_pad(256) == 256
     torch.manual_seed(3)
     blk = Block(dim, heads, qkv_bias=True, proj_drop=0.1, attn_drop=0.1, drop_path=0.1).cuda().train()
     x0 = (torch.randn(2, 256, dim, device="cuda") * 0.5).to(torch.bfloat16)

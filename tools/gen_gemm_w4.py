@@ -117,6 +117,8 @@ def gen(a_kc, b_kc, cfg):
         e("s_mov_b64 s[%d:%d], %s" % (S, S + 1, base))
         e("s_mov_b32 s%d, 0x7fffffff" % (S + 2))
         e("s_mov_b32 s%d, 0x00020000" % (S + 3))
+    if cfg.get("pace"):
+        e("s_mov_b32 s97, 0")
     e("s_mov_b32 s%d, %%[ldswa]" % S_WA)
     e("s_mov_b32 s%d, %%[ldswb]" % S_WB)
     e("s_lshl_b32 s%d, s%d, 1" % (S_TA, S_WA))               # stage flip of a write base: base <- (2 base0 + STAGE) - base
@@ -178,10 +180,47 @@ def gen(a_kc, b_kc, cfg):
         gaps[g_ - 1].append(setm0)
         gaps[g_].append(ld)
     b2 = cfg["bar2"]
+    if cfg.get("pace"):
+        # cohort pacing (the weight-gradient form; csrc/gemm.hip w4_cohort_start): every P-th K-tile, in front of bar2, the wave that
+        # holds the cohort's counter (%[pcp] != 0: wave 0 of a paced launch) adds its arrival and polls -- bounded -- until the
+        # whole cohort (the XCD's workgroups of this round, %[pcn] of them) has arrived; the other waves wait at bar2's s_barrier.
+        # A cohort's column groups sweep at rates 3-5 % apart (memory-side); L2 holds ~10 K-tiles of the cohort's strips: a
+        # check every P = 64 K-tiles keeps them within 2-3.  v128 / v129 are dead here (the X fragments of K-tile t were used
+        # up in slots 0-63 and those of t + 1 are read after bar2); s96-s99 are scratch (s97 = the running target, s[98:99] = exec).
+        P = cfg["pace"]
+        gaps[b2] += [
+            "s_and_b32 s96, s%d, %d" % (S_T, P - 1),
+            "s_cmp_eq_u32 s96, %d" % (P - 1),
+            "s_cbranch_scc0 o2w4_np_%=",
+            "s_cmp_eq_u64 %[pcp], 0",
+            "s_cbranch_scc1 o2w4_np_%=",
+            "s_mov_b64 s[98:99], exec",
+            "s_mov_b64 exec, 1",                               # one lane: one arrival, one polled dword
+            "v_mov_b32 v129, 0",
+            "v_mov_b32 v128, 1",
+            "global_atomic_add v129, v128, %[pcp] sc1",
+            "s_add_u32 s97, s97, %[pcn]",
+            "s_mov_b32 s%d, %d" % (S_X, cfg.get("pace_polls", 24)),     # (S_X / S_X2 are free outside the K-advance gaps)
+            "o2w4_pl_%=:",
+            "global_load_dword v128, v129, %[pcp] sc1",
+            "s_waitcnt vmcnt(0)",
+            "v_readfirstlane_b32 s%d, v128" % S_X2,
+            "s_nop 0",
+            "s_cmp_ge_u32 s%d, s97" % S_X2,
+            "s_cbranch_scc1 o2w4_pd_%=",
+            "s_sleep 4",
+            "s_sub_u32 s%d, s%d, 1" % (S_X, S_X),
+            "s_cmp_lg_u32 s%d, 0" % S_X,
+            "s_cbranch_scc1 o2w4_pl_%=",
+            "o2w4_pd_%=:",
+            "s_mov_b64 exec, s[98:99]",
+            "o2w4_np_%=:",
+        ]
     gaps[b2] += ["s_waitcnt vmcnt(%d)" % sum(1 for x in lg if x < b2), "s_barrier"]
     ka_ = k_advance(["s_add_u32 s%d, s%d, 3" % (S_X, S_T)], cfg.get("kwrap", 0))
     ga = max(lg) + 1
     assert ga + 3 <= 125, "pieces run too late"
+    assert not cfg.get("pace") or not (ga <= b2 <= ga + 2), "the pacing code borrows S_X / S_X2: keep it out of the K-advance gaps"
     if cfg.get("kwrap"):
         gaps[ga] += ka_[:7]                      # (ablation) s_cmp + s_cselects stay together (SCC)
         gaps[ga + 1] += ka_[7:11]                # s_add / s_addc pairs stay together (carry)
@@ -250,6 +289,15 @@ def gen(a_kc, b_kc, cfg):
     e("s_cmp_lt_u32 s%d, %%[nk]" % S_T)
     e("s_cbranch_scc1 o2w4_loop_%=")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if cfg.get("pace"):
+        # (after the drain: the last X reads land in v128.. too)  a workgroup that leaves its sweep credits the cohort's counter beyond any target (targets stay below 32 x 2048 / P): in a
+        # cohort whose members sweep contractions of different lengths the ones still sweeping then pass every later check at once
+        # instead of waiting out the poll budget for a member that is gone
+        L += ["s_cmp_eq_u64 %[pcp], 0", "s_cbranch_scc1 o2w4_nc_%=",
+              "s_mov_b64 s[98:99], exec", "s_mov_b64 exec, 1",
+              "v_mov_b32 v129, 0", "v_mov_b32 v128, 0x100000",
+              "global_atomic_add v129, v128, %[pcp] sc1",
+              "s_mov_b64 exec, s[98:99]", "o2w4_nc_%=:"]
     e("s_nop 7")
     e("s_nop 7")
     e("s_mov_b32 m0, s%d" % S_M0)
@@ -268,7 +316,7 @@ def gen_cstage(hh):
     return L
 
 
-BASE = dict(bar1_lag=6, lstride=6, bar2=90, xstride_kc=2)
+BASE = dict(bar1_lag=6, lstride=6, bar2=90, xstride_kc=2, pace=64)
 FORMS = {"NT": (True, True), "NN": (True, False), "TN": (False, False), "TT": (False, True)}
 
 
@@ -285,10 +333,12 @@ def emit(path):
         macro("O2_W4_CSTAGE%d" % hh, gen_cstage(hh))
     for name, (a_kc, b_kc) in FORMS.items():
         cfg = dict(BASE)
+        if name != "TN":
+            cfg.pop("pace", None)                # (pacing lives in the weight-gradient form only)
         if cfg.get("kwrap_tn"):                  # (ablation restricted to the weight-gradient form: a step's activations stay right)
             cfg["kwrap"] = cfg["kwrap_tn"] if name == "TN" else 0
         macro("O2_W4_ASM_%s" % name, gen(a_kc, b_kc, cfg))
-        macro("O2_W4_ASM_%s_STAMP" % name, gen(a_kc, b_kc, dict(BASE, stamp=True)))
+        macro("O2_W4_ASM_%s_STAMP" % name, gen(a_kc, b_kc, dict(BASE, stamp=True, pace=0)))
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"a%d"' % r for r in range(256)] + ['"v%d"' % r for r in range(128, 256)] + \
            ['"s%d"' % r for r in range(64, 100)]
     out.append("#define O2_W4_CLOBBERS \\")

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "orbit-2_amd")]
 import torch
 from climate_learn import _hip
-_hip.LIB_PATH = os.path.join(ROOT, "orbit-2_amd", "lib", "alt", "w4trace.so")
+_hip.LIB_PATH = os.environ.get("ORBIT2_TRACE_LIB", os.path.join(ROOT, "orbit-2_amd", "lib", "alt", "w4trace.so"))
 T, D = 131072, 3072
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(torch.bfloat16)
 pad = lambda n: n + 64 if (2 * n) % 8192 == 0 else n
