@@ -81,7 +81,13 @@ int orbit2_gemm_bf16_colsum_rows(const orbit2_gemm_args* args);   /* 0: this cal
 /* n (<= ORBIT2_GEMM_MAX_GROUP) independent problems of ONE operand form (same a_kc, b_kc) in one launch (the 256x256
  * 8-phase kernel when every problem has K % 64 == 0, M, N >= 256 and the group fills the chip; the 128x128 kernel
  * otherwise): the partially filled last round of each problem is filled with the next one's tiles.  Used for
- * the four weight-gradient GEMMs of a Block (reference: autograd of attention.py:36,40 + mlp.py:50,54). */
+ * the four weight-gradient GEMMs of a Block (reference: autograd of attention.py:36,40 + mlp.py:50,54).
+ * Round 6 (same ABI version: no signature or layout changed, the limit only grew from 8): up to 12 problems, so that a caller can
+ * hand over the tiles beyond the group's last whole round of 256 as part-length problems over slices of the contraction (the
+ * Python layer's balanced weight-gradient launch: 3 full problems + 2 x 4 quarter-length ones, partial products summed by
+ * orbit2_batch_sum).  When every problem sweeps >= 512 K-tiles of 64 the workgroups of an XCD start their tiles together
+ * (a bounded wait on a self-cleaning counter in a static device array: a pacing hint, never needed for correctness;
+ * ORBIT2_W4_PACE = 0 / 1 / 2: off / on (default) / plus check points inside the sweep). */
 #define ORBIT2_GEMM_MAX_GROUP 12
 int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, void* stream);
 

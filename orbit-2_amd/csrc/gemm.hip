@@ -1368,7 +1368,11 @@ extern "C" int orbit2_gemm_bf16_grouped(const orbit2_gemm_args* args, int n, voi
       dim3 grid(total), block(256);
       // cohort start barrier: every problem's tiles sweep >= 512 K-tiles (a round lasts >= 0.6 ms: the bounded wait is noise
       // against it, and a lost cohort costs a whole sweep of re-fetched strips)
-      static const int pace_env = [] { const char* e = getenv("ORBIT2_W4_PACE"); return e ? atoi(e) : 2; }();   // 0 off, 1 start barrier, 2 + in-sweep
+      // ORBIT2_W4_PACE: 0 off, 1 (default) the cohort start barrier, 2 + the check points inside the sweep.  2 brings the launch's
+      // bytes beyond L2 to the tile-walk bound (48 GB, 3.7 x algorithmic; 1.71 GHz stand-alone) and -2.3 % stand-alone, but the
+      // SAME time in the step (166.6 vs 166.6 ms per step, profiles/r06_pace2b_instep.txt): every column group then sweeps at the
+      // slowest group's rate, which is what a round takes anyway.  Kept selectable, not default.
+      static const int pace_env = [] { const char* e = getenv("ORBIT2_W4_PACE"); return e ? atoi(e) : 1; }();
       int kmin = args[0].K;
       for (int i = 1; i < n; ++i) kmin = args[i].K < kmin ? args[i].K : kmin;
       g.pace = (O2_W4_WALK && pace_env && kmin >= 512 * BK3 && total > 256) ? pace_env : 0;
