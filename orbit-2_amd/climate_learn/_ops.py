@@ -726,6 +726,8 @@ class TokenTablesFn(torch.autograd.Function):
         w0, ws, b0, bs = layout["w0"], layout["ws"], layout["b0"], layout["bs"]
         ctx.layout, ctx.ids_t, ctx.V, ctx.D = layout, ids_t, V, D
         ctx.params = (var_embed,) + tuple(te_params)
+        if "pending" in layout:
+            layout["pending"][0] += 1                     # an instance of this step is outstanding until its backward has run
         return _hip.tables_gather(w0.data, ws, b0.data, bs, var_embed.data.reshape(-1, D), ids_t, V, D)
 
     @staticmethod
@@ -739,6 +741,8 @@ class TokenTablesFn(torch.autograd.Function):
                             ctx.V, ctx.D)
         for p in ctx.params:                              # the engine counts these parameters as arrived (no AccumulateGrad runs)
             p._o2_engine.grad_ready(p)
+        if "pending" in lay:
+            lay["pending"][0] = max(0, lay["pending"][0] - 1)
         return (None,) * (5 + len(ctx.params) - 1)
 
 

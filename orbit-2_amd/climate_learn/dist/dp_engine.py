@@ -268,6 +268,9 @@ class HipDataParallel(nn.Module):
     def zero_grad(self, set_to_none: bool = False):
         """Logical zero: bf16 buckets are overwritten (beta = 0) by the first backward kernel that touches
         them; the fp32 bucket is accumulated into by autograd, so it is memset."""
+        pend = getattr(self.module, "_tables_pending", None)      # (a forward whose backward never ran must not pin the model
+        if pend is not None:                                         #  to the ATen table path: a new step starts clean)
+            pend[0] = 0
         self.g32.zero_()
         for bk in self.buckets:
             bk.pending = sum(1 for p in bk.params if p.requires_grad)

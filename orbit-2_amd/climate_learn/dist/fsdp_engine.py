@@ -446,6 +446,9 @@ class HipFullyShardedDataParallel(nn.Module):
 
     # ---- gradient life cycle -----------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
+        pend = getattr(self.module, "_tables_pending", None)      # (a forward whose backward never ran must not pin the model
+        if pend is not None:                                         #  to the ATen table path: a new step starts clean)
+            pend[0] = 0
         self.g32.zero_()
         for u in self.units:
             u.pending = sum(1 for p in u.params if p.requires_grad)

@@ -166,6 +166,24 @@ class Res_Slim_ViT(nn.Module):
         if ids_t is None:
             ids_t = self._idx_cache[key] = torch.tensor(list(ids), dtype=torch.long, device=wq.device)
         lay = self._token_tables_layout() if torch.is_grad_enabled() else None
+        # the fused path's backward adds into the gradient rows WITHOUT atomics, one workgroup per id, and announces the parameters
+        # to the engine itself: it needs distinct variable ids (a duplicated id would make two workgroups race on one row -- the
+        # ATen path accumulates duplicates correctly) and at most ONE instance per backward (two forwards feeding one backward: the
+        # first node's `grad_ready` would launch the bucket's all-reduce before the second node's rows have landed).  (advisor r5)
+        pending = self.__dict__.setdefault("_tables_pending", [0])
+        if lay is not None and pending[0] > 0:
+            eng = getattr(self.var_embed, "_o2_engine", None)
+            reduces = getattr(eng, "comm", None)              # (sharding engine) / world, force_comm (replicated engine)
+            if reduces is None:
+                reduces = getattr(eng, "world", 1) > 1 or getattr(eng, "force_comm", False)
+            if reduces and getattr(self, "fused_tables", True):
+                # with collectives the outstanding fused node will announce the table parameters when ITS backward has run: a
+                # second use of them in the same backward (this forward) could land after the bucket's all-reduce was launched
+                raise RuntimeError("Res_Slim_ViT: a second forward before the previous one's backward, under a data-parallel engine: "
+                                   "set model.fused_tables = False (the ATen table path accumulates any number of uses)")
+            lay = None
+        if lay is not None and (len(set(ids)) != len(ids) or not getattr(self, "fused_tables", True)):
+            lay = None
         if lay is not None:
             # engine-managed parameters at a uniform pitch: one launch forward, one backward that accumulates straight into
             # the engine's gradient bucket (no stack / transpose / cat, no per-parameter autograd accumulation)
@@ -174,6 +192,7 @@ class Res_Slim_ViT(nn.Module):
             if ids32 is None:
                 ids32 = self._idx_cache[k32] = ids_t.to(torch.int32)
             flat = [te.weight for te in tes] + [te.bias for te in tes]
+            lay = dict(lay, pending=pending)
             cmat = _ops.TokenTablesFn.apply(lay, ids32, len(ids), D, self.var_embed, *flat)
         else:
             w4 = torch.stack([te.weight.view(D, 4) for te in tes]).transpose(1, 2)    # [V, 4, D]

@@ -707,3 +707,29 @@ def test_token_tables_fused_path_equals_the_aten_path(golden_dir):
             touched += 1
             assert torch.equal(a, b), (n, step, float((a - b).abs().max()))
         assert touched == 2 * len(c["in_vars"]) + 1
+    # advisor r5: a DUPLICATED variable id (two input channels of one variable) must not take the fused scatter (one workgroup per
+    # id adds into the gradient rows without atomics): the engine-managed model falls back to the ATen path and still equals the
+    # plain one bit for bit; a second forward before the first one's backward falls back too
+    dup_vars = list(c["in_vars"]) + [c["in_vars"][-1]]
+    xd = torch.cat([batch[0], batch[0][:, -1:]], 1)
+    eng.zero_grad()
+    for p in plain.parameters():
+        p.grad = None
+    lm = training_step((xd, batch[1], dup_vars, c["out_vars"]), 0, eng, torch.device("cuda"), VW, lossf)
+    assert managed._tables_pending[0] == 0                                   # the fused node was not used
+    lm.backward()
+    eng.finish_grad_sync()
+    lp = training_step((xd, batch[1], dup_vars, c["out_vars"]), 0, plain, torch.device("cuda"), VW, lossf)
+    lp.backward()
+    assert float(lm) == float(lp)
+    for n in names:
+        if gp[n].grad is not None:
+            assert torch.equal(gm[n].grad, gp[n].grad), n
+    eng.zero_grad()
+    l1 = training_step(batch, 0, eng, torch.device("cuda"), VW, lossf)
+    assert managed._tables_pending[0] == 1
+    l2 = training_step(batch, 0, eng, torch.device("cuda"), VW, lossf)       # second forward, first backward still due: ATen path
+    assert managed._tables_pending[0] == 1
+    (l1 + l2).backward()
+    eng.finish_grad_sync()
+    assert managed._tables_pending[0] == 0
