@@ -825,11 +825,11 @@ extern "C" int orbit2_debug_read_w4(unsigned int* host_dst, int n) {
 // diagnostic build only (tools/w4_trace.py): when did each workgroup start its K sweep and when did it end it -- s_memrealtime
 // (100 MHz) of wave 0 at the statement's entry and exit, [blockIdx][2]: the start spread of a round's XCD cohort and the drift
 // between its workgroups over a sweep
-__device__ unsigned long long o2_w4_trace[8192 * 2];
+__device__ unsigned long long o2_w4_trace[32768 * 2];
 extern "C" int orbit2_debug_read_w4_trace(unsigned long long* host_dst, int n) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(o2_w4_trace), sizeof(unsigned long long) * (size_t)n);
 }
-#define O2_W4_TRACE_POINT(k) if (tid == 0 && blockIdx.x < 8192) o2_w4_trace[blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memrealtime()
+#define O2_W4_TRACE_POINT(k) if (tid == 0 && blockIdx.x < 32768) o2_w4_trace[blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define O2_W4_TRACE_POINT(k)
 #endif
