@@ -1102,6 +1102,9 @@ __device__ __forceinline__ void gemm256w_tile(const bf16_t* __restrict__ A, cons
     }
     return;
   }
+  // (measured and not kept, round 6: the lean epilogue straight from the accumulator registers -- no LDS image, no barrier, 64
+  // stores of 16 rows x 32 B per wave, bit-identical: 1-3 % SLOWER on the K = 3072 GEMMs, level on K = 12288; the 32-byte row
+  // segments cost the store path more than the two LDS passes cost the workgroup.  profiles/r06_direct_epilogue_ab.txt)
   if (generic && epi.bias) unpack8(*reinterpret_cast<const u32x4*>(epi.bias + ne), bias8);
 #pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
