@@ -179,3 +179,38 @@ def test_weight_gradient_group_balance_plan():
     assert _dw_balance_plan([(4, 4), (4, 4)], 4) is None          # fewer tiles than one round
     assert _dw_balance_plan([(16, 16)], 4) is None                # already whole rounds
     assert _dw_balance_plan([(36, 12), (12, 12), (48, 12), (12, 48)], 0) is None
+
+
+def test_round_major_tile_ids_are_a_bijection():
+    """mirror of csrc/gemm.hip:xcd_round_tile_id (block b runs on XCD b & 7; the 256 blocks of a round take 256 consecutive ids,
+    each XCD a consecutive run of them) and of gemm256w_tile's id -> (tm, tn) walk incl. the column-major form of wide problems:
+    every tile exactly once for any grid size, a round's ids contiguous, an XCD's ids of a round contiguous"""
+    def rid(b, nwg):
+        base = b & ~255
+        cnt = min(256, nwg - base)
+        x, s = b & 7, (b & 255) >> 3
+        q8, r8 = cnt >> 3, cnt & 7
+        return base + (x * (q8 + 1) if x < r8 else r8 * (q8 + 1) + (x - r8) * q8) + s
+
+    for nwg in (1, 7, 8, 9, 255, 256, 257, 300, 511, 512, 1000, 1728, 6144, 6145):
+        ids = [rid(b, nwg) for b in range(nwg)]
+        assert sorted(ids) == list(range(nwg)), nwg
+        for r0 in range(0, nwg, 256):
+            rnd = ids[r0:r0 + 256]
+            assert min(rnd) == r0 and max(rnd) == min(nwg, r0 + 256) - 1
+            for x in range(8):
+                mine = sorted(i for b, i in zip(range(r0, r0 + len(rnd)), rnd) if b & 7 == x)
+                assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True
+
+    def walk(i, tiles_m, tiles_n, group=4):
+        tw = tiles_n > tiles_m
+        t_major, t_minor = (tiles_n, tiles_m) if tw else (tiles_m, tiles_n)
+        per_group = group * t_minor
+        first = (i // per_group) * group
+        gsz = min(group, t_major - first)
+        ta, tb = first + (i % per_group) % gsz, (i % per_group) // gsz
+        return (tb, ta) if tw else (ta, tb)
+
+    for tm, tn in ((36, 12), (12, 12), (48, 12), (12, 48), (5, 3), (3, 5), (1, 9), (512, 12), (7, 7)):
+        seen = {walk(i, tm, tn) for i in range(tm * tn)}
+        assert seen == {(a, b) for a in range(tm) for b in range(tn)}, (tm, tn)
