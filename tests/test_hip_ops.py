@@ -170,6 +170,42 @@ def test_gemm_grouped_dw_4wave_equals_8phase_at_the_bench_size(hip):
     assert nerr(res[258][2][:4, :8], ref.cpu()) < 6e-3
 
 
+def child_gemm_grouped_dw_with_cohort_pacing():
+    """body of the next test (ORBIT2_W4_PACE is read once per process): the same comparison under pacing mode 2"""
+    from climate_learn import _hip
+    assert os.environ.get("ORBIT2_W4_PACE") == "2"
+    test_gemm_grouped_dw_4wave_equals_8phase_at_the_bench_size(_hip)
+    # mixed-length cohorts: problems of 2048 and 512 K-tiles in one launch (the balanced launch's shape) -- a workgroup that
+    # leaves its sweep credits the cohort's counter, nobody waits out the poll budget; results = the single launches', bit for bit
+    T, D = 131072, 3072
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda r, c: (torch.randn(r, c, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    dy, x = rnd(T, 1024), rnd(T, D)
+    outs = [torch.empty(1024, D, dtype=torch.bfloat16, device="cuda") for _ in range(10)]
+    q = T // 4
+    probs = []
+    for rep in range(2):                               # 10 problems = 480 tiles: two rounds, full and quarter sweeps in one cohort
+        probs.append((dy, x, outs[5 * rep], 1024, D, T, 1024, D, D, dict(a_kc=False, b_kc=False)))
+        probs += [(dy[i * q:(i + 1) * q], x[i * q:(i + 1) * q], outs[5 * rep + 1 + i], 1024, D, q, 1024, D, D, dict(a_kc=False, b_kc=False))
+                  for i in range(4)]
+    _hip.gemm_grouped(probs)
+    torch.cuda.synchronize()
+    ref = [torch.empty(1024, D, dtype=torch.bfloat16, device="cuda") for _ in range(10)]
+    for (a, b, _, M, N, K, lda, ldb, ldc, kw), o in zip(probs, ref):
+        _hip.gemm(a, b, o, M, N, K, lda, ldb, ldc, tile=256, **kw)
+    torch.cuda.synchronize()
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
+
+
+def test_gemm_grouped_dw_with_cohort_pacing():
+    """ORBIT2_W4_PACE=2 (check points inside the sweep: generated code in the TN loop that the default mode jumps over): the
+    bench-size weight-gradient group still equals the 8-phase kernel bit for bit, also with sweeps of different lengths in one
+    cohort (the exit credit), and the launch ends (bounded polls)"""
+    from tests._child import run_child
+    run_child(__file__, "child_gemm_grouped_dw_with_cohort_pacing", timeout=600, env={"ORBIT2_W4_PACE": "2"})
+
+
 def test_gemm_4wave_kernel_takes_whole_tiles_only(hip):
     A, B = bf(torch.randn(264, 128)).cuda(), bf(torch.randn(256, 128)).cuda()
     out = torch.empty(264, 256, dtype=torch.bfloat16, device="cuda")
