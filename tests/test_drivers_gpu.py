@@ -375,3 +375,17 @@ def test_bench_other_configs_and_npz_leg(tmp_path):
     assert n["value"] > 0 and n["resident_value"] == d["value"] and abs(n["ratio_to_resident"] - n["value"] / d["value"]) < 1e-9
     assert n["workers"] == 2 and n["loader_cpu_s_per_sample"] > 0 and n["tree"]["low_res"] == [32, 64] and n["tree"]["high_res"] == [128, 256]
     assert "npz" in d["data"]
+
+
+def test_bench_sharded_engine_with_graph_replay(tmp_path):
+    """round 6: `--fsdp --graph on` is no longer refused -- the parameter-sharding engine's step is captured in its single-stream
+    form and replayed; the line reports the captured configuration and a finite loss"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--model", "interm_8m",
+                        "--grid", "32x64", "--batch", "2", "--no-cpu-baseline", "--fsdp", "--graph", "on"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.splitlines()[-1])
+    assert d["config"]["hipgraph"] is True and d["value"] > 0
+    loss = d["step_model"]["final_loss"]
+    assert loss == loss and 0 < loss < 1e4
