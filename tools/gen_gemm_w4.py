@@ -333,8 +333,9 @@ def emit(path):
         macro("O2_W4_CSTAGE%d" % hh, gen_cstage(hh))
     for name, (a_kc, b_kc) in FORMS.items():
         cfg = dict(BASE)
-        if name != "TN":
-            cfg.pop("pace", None)                # (pacing lives in the weight-gradient form only)
+        if name != "TN" or cfg.get("kwrap") or cfg.get("kwrap_tn"):
+            cfg.pop("pace", None)                # (pacing lives in the weight-gradient form only; the wrap ablation borrows its scratch
+                                                 #  registers s96 / s97, so the two never share a loop)
         if cfg.get("kwrap_tn"):                  # (ablation restricted to the weight-gradient form: a step's activations stay right)
             cfg["kwrap"] = cfg["kwrap_tn"] if name == "TN" else 0
         macro("O2_W4_ASM_%s" % name, gen(a_kc, b_kc, cfg))
