@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 // Each wave walks LN_RPW consecutive rows (two passes per row: statistics, then dx from the L1/L2-hot
 // lines) and keeps its dgamma/dbeta partial sums in registers; one partial row per block (D % 4 == 0).
 constexpr int LN_RPW = 16;
+#ifndef O2_LN_FMA
+#define O2_LN_FMA 1      // row-shared backward: the fused-multiply-add form of xhat and of dx (0: the expressions of rounds 2-5, A/B builds)
+#endif
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                      const bf16_t* __restrict__ gamma, const float* __restrict__ mean,
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
   for (int rr = 0; rr < nrow; ++rr) {
     const int row = row0 + rr;
     const float mu = mean[row], rs = rstd[row];
+    const float nmurs = -mu * rs;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCW; ++c) {
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
         unpack8(xp[c], xv); unpack8(dp[c], dv); unpack8(gp[c], gv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xhat = (xv[j] - mu) * rs;
+          const float xhat = O2_LN_FMA ? fmaf(xv[j], rs, nmurs) : (xv[j] - mu) * rs;     // (x - mu) rs as ONE fma
           const float g = dv[j] * gv[j];
           s1 += g; s2 += g * xhat;
           dg[c][j] += dv[j] * xhat; db[c][j] += dv[j];
@@ -244,6 +248,9 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
 #pragma unroll
     for (int w = 0; w < TPB / 64; ++w) { s1 += red[rr & 1][w][0]; s2 += red[rr & 1][w][1]; }
     s1 /= (float)D; s2 /= (float)D;
+    // dx = rs (dy g - s1 - xhat s2) = dy (g rs) + x c2 + c0 with the row's c2 = -rs^2 s2, c0 = rs (mu rs s2 - s1): three
+    // instructions per element (one multiply, two fused multiply-adds) instead of seven -- the kernel is co-limited by vector issue
+    const float c2 = -rs * rs * s2, c0 = rs * (mu * rs * s2 - s1);
 #pragma unroll
     for (int c = 0; c < NCW; ++c) {
       const int ch = tid + c * TPB;
@@ -251,7 +258,8 @@ __global__ __launch_bounds__(TPB) void ln_bwd_wide_kernel(const bf16_t* __restri
         float xv[8], dv[8], gv[8], o[8];
         unpack8(xp[c], xv); unpack8(dp[c], dv); unpack8(gp[c], gv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = rs * (dv[j] * gv[j] - s1 - (xv[j] - mu) * rs * s2);
+        for (int j = 0; j < 8; ++j)
+          o[j] = O2_LN_FMA ? fmaf(xv[j], c2, fmaf(dv[j], gv[j] * rs, c0)) : rs * (dv[j] * gv[j] - s1 - (xv[j] - mu) * rs * s2);
         if (dres) {
           float rv[8];
           unpack8(rp[c], rv);
