@@ -308,3 +308,50 @@ def test_interm_1b_model_batch_independence_and_determinism():
     assert y2.shape == (2, 3, 512, 1024) and torch.isfinite(y2).all()
     assert torch.equal(y2, y2b)
     assert torch.equal(y2[1:2], y1)
+
+
+def test_balanced_weight_gradient_group_at_the_bench_batch(hip, monkeypatch):
+    """round 6, _ops._dw_balance at the headline size (131072 tokens; the Block's four weight gradients = 1728 tiles = 6.75 rounds):
+    the tail tiles (all of proj + the last 4 tile rows of qkv) are split 4 ways over the tokens, bf16 partials summed in fp32.
+    Against the unbalanced group: every full-length tile bit for bit, the split rows to the partials' bf16 rounding; with beta = 1 the
+    sum lands on top of an existing gradient; bit-repeatable; sampled entries against fp64 dot products."""
+    from climate_learn import _ops
+    T, D = 131072, D_
+    g = torch.Generator(device="cuda").manual_seed(9)
+    mk = lambda c: (torch.randn(T, _ops._ld_pad(c), device="cuda", generator=g) * 0.25).to(BF)[:, :c]
+    shapes = ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D))
+    ops = [(mk(no), mk(ni)) for no, ni in shapes]
+
+    def run(balance, beta, init):
+        monkeypatch.setattr(_ops, "_DW_BALANCE", balance)
+        outs = [init[i].clone() if init is not None else torch.empty(no, ni, dtype=BF, device="cuda") for i, (no, ni) in enumerate(shapes)]
+        probs = [(dy, x, o, no, ni, T, dy.stride(0), x.stride(0), ni, dict(a_kc=False, b_kc=False, beta=beta))
+                 for (dy, x), o, (no, ni) in zip(ops, outs, shapes)]
+        probs2, sums = _ops._dw_balance(probs)
+        assert (len(probs2) > len(probs)) == bool(balance) and (len(sums) == 2) == bool(balance)
+        hip.gemm_grouped(probs2)
+        for parts, S, rows, K, dst, b in sums:
+            hip.batch_sum(parts, S, rows, K, dst, beta=b)
+        torch.cuda.synchronize()
+        return outs
+
+    plain = run(0, 0.0, None)
+    bal = run(4, 0.0, None)
+    bal2 = run(4, 0.0, None)
+    for a, b in zip(bal, bal2):
+        assert torch.equal(a, b)                                          # fixed summation order
+    assert torch.equal(plain[2], bal[2]) and torch.equal(plain[3], bal[3])     # fc1, fc2: untouched problems
+    cut = 3 * D - 4 * 256
+    assert torch.equal(plain[0][:cut], bal[0][:cut])                      # qkv's full-length tile rows
+    for a, b in ((plain[0][cut:], bal[0][cut:]), (plain[1], bal[1])):   # the split rows: four bf16-rounded partials
+        err = (a.float() - b.float()).abs().max() / a.float().abs().max()
+        assert float(err) < 1.5e-2, float(err)
+    dy, x = ops[1]                                                        # proj: sampled entries against fp64
+    rows_, cols_ = torch.randint(0, D, (64,), device="cuda"), torch.randint(0, D, (64,), device="cuda")
+    ref = (dy[:, rows_].double() * x[:, cols_].double()).sum(0)
+    got = bal[1][rows_, cols_].double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2
+    init = [torch.full((no, ni), 0.5, dtype=BF, device="cuda") for no, ni in shapes]
+    acc = run(4, 1.0, init)                                               # accumulation into an existing gradient
+    d = (acc[1].float() - 0.5 - bal[1].float()).abs().max() / bal[1].float().abs().max()
+    assert float(d) < 2e-2, float(d)
